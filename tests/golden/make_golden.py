@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference).  It imports the reference's
+unmodified (L)-path modules -- cldm.cldm.{ControlNet, ControlledUnetModel},
+cldm.ddim_hacked.DDIMSampler, ControlLDM.apply_model (called unbound on a shim) --
+feeds them the seeded synthetic weights/inputs of prompt-diffusion_amd/weights.py and
+stores inputs-by-seed + expected outputs as small .npz files.  Nothing of the reference's
+source is stored; fixtures are data only.
+
+Harness-side stubs (touch no arithmetic): pytorch_lightning / omegaconf / torchvision are
+absent in this image and only needed by training code at module import.
+DDIMSampler.register_buffer is overridden because the stock one force-moves buffers to
+"cuda" (cldm/ddim_hacked.py:17-21) and there is no GPU here.
+
+Usage: python tests/golden/make_golden.py [--skip-sd15]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def install_stubs():
+    import torch.nn as nn
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = type("LightningModule", (nn.Module,), {})
+    plu = types.ModuleType("pytorch_lightning.utilities")
+    plr = types.ModuleType("pytorch_lightning.utilities.rank_zero")
+    plr.rank_zero_only = lambda f: f
+    plu.rank_zero = plr
+    plu.rank_zero_only = plr.rank_zero_only
+    plud = types.ModuleType("pytorch_lightning.utilities.distributed")
+    plud.rank_zero_only = plr.rank_zero_only
+    pl.utilities = plu
+    oc = types.ModuleType("omegaconf")
+    ocl = types.ModuleType("omegaconf.listconfig")
+    ocl.ListConfig = type("ListConfig", (list,), {})
+    oc.listconfig = ocl
+    oc.ListConfig = ocl.ListConfig
+    oc.OmegaConf = type("OmegaConf", (), {})
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = None
+    tv.utils = tvu
+    for name, mod in [("pytorch_lightning", pl), ("pytorch_lightning.utilities", plu),
+                      ("pytorch_lightning.utilities.rank_zero", plr),
+                      ("pytorch_lightning.utilities.distributed", plud),
+                      ("omegaconf", oc), ("omegaconf.listconfig", ocl),
+                      ("torchvision", tv), ("torchvision.utils", tvu)]:
+        sys.modules.setdefault(name, mod)
+
+
+def ref_kwargs(cfg):
+    return dict(image_size=32, in_channels=cfg.in_channels, model_channels=cfg.model_channels,
+                attention_resolutions=list(cfg.attention_resolutions), num_res_blocks=cfg.num_res_blocks,
+                channel_mult=list(cfg.channel_mult), num_heads=cfg.num_heads, use_spatial_transformer=True,
+                transformer_depth=1, context_dim=cfg.context_dim, use_checkpoint=False, legacy=False)
+
+
+def build_reference(cfg, W):
+    """Instantiate the reference networks and load the synthetic recipe into them."""
+    from cldm.cldm import ControlNet, ControlledUnetModel, ControlLDM
+    import cldm.cldm as cldm_mod
+    kw = ref_kwargs(cfg)
+    cn = ControlNet(hint_channels=cfg.hint_channels, **kw)
+    if tuple(cfg.hint_widths) != (16, 16, 32, 32, 96, 96, 256):
+        # reduced test network: same 8-conv structure, narrower widths
+        from ldm.modules.diffusionmodules.util import conv_nd
+        from ldm.modules.diffusionmodules.openaimodel import TimestepEmbedSequential
+        import torch.nn as nn
+
+        def mk(cin):
+            mods = []
+            for l in W.hint_layout(cfg, cin):
+                mods.append(conv_nd(2, l["cin"], l["cout"], 3, padding=1, stride=l["stride"]))
+                if l["silu"]:
+                    mods.append(nn.SiLU())
+            return TimestepEmbedSequential(*mods)
+        cn.input_hint_block = mk(cfg.hint_channels)
+        cn.input_cond_block = mk(cfg.query_channels)
+    un = ControlledUnetModel(out_channels=cfg.out_channels, **kw)
+    spec_u = {n[len(W.UNET_PREFIX):]: s for n, s, _ in W.unet_spec(cfg)}
+    spec_c = {n[len(W.CNET_PREFIX):]: s for n, s, _ in W.controlnet_spec(cfg)}
+    for mod, spec, prefix in ((un, spec_u, W.UNET_PREFIX), (cn, spec_c, W.CNET_PREFIX)):
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(spec.keys()), "parameter inventory/order mismatch vs reference"
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
+        kinds = {n: k for n, _, k in W.param_spec(cfg)}
+        new = {k: torch.from_numpy(W.synth_tensor(prefix + k, v.shape, kinds[prefix + k])) for k, v in sd.items()}
+        mod.load_state_dict(new, strict=True)
+        mod.eval()
+
+    class Shim:  # the attributes ControlLDM.apply_model / DDIMSampler read
+        pass
+    m = Shim()
+    m.model = types.SimpleNamespace(diffusion_model=un)
+    m.control_model = cn
+    m.control_scales = [1.0] * 13
+    m.only_mid_control = False
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    betas = make_beta_schedule("linear", cfg.timesteps, linear_start=cfg.linear_start, linear_end=cfg.linear_end)
+    ac = np.cumprod(1.0 - betas, axis=0)
+    m.betas = torch.tensor(betas, dtype=torch.float32)                     # ddpm.py:155-159
+    m.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+    m.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+    m.num_timesteps = cfg.timesteps
+    m.parameterization = "eps"
+    m.device = torch.device("cpu")
+    m.apply_model = lambda x, t, c: ControlLDM.apply_model(m, x, t, c)
+    return m, cn, un
+
+
+def make_sampler(model):
+    from cldm.ddim_hacked import DDIMSampler
+
+    class CPUSampler(DDIMSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+    return CPUSampler(model)
+
+
+def t2n(x):
+    return x.detach().cpu().numpy().astype(np.float32)
+
+
+def subsample(x, n=4096):
+    f = x.reshape(-1)
+    stride = max(1, f.size // n)
+    return f[::stride][:n].copy(), stride
+
+
+def run_net_case(tag, cfg, W, B, h, w, S, cfg_scale, eta, out):
+    model, cn, un = build_reference(cfg, W)
+    inp = W.synth_inputs(cfg, B, h, w)
+    tt = {k: torch.from_numpy(v) for k, v in inp.items()}
+    cond = {"c_crossattn": [tt["ctx_cond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    uc = {"c_crossattn": [tt["ctx_uncond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    sampler = make_sampler(model)
+    with torch.no_grad():
+        # one apply_model at the first timestep on the CFG batch, with the 13 residuals
+        sampler.make_schedule(S, ddim_eta=eta, verbose=False)
+        step = int(np.flip(sampler.ddim_timesteps)[0])
+        x_in = torch.cat([tt["x_T"]] * 2)
+        t_in = torch.full((2 * B,), step, dtype=torch.long)
+        ctx = torch.cat([tt["ctx_uncond"], tt["ctx_cond"]])
+        pair = torch.cat([tt["pair"]] * 2)
+        qry = torch.cat([tt["query"]] * 2)
+        control = cn(x=x_in, timesteps=t_in, example_pair=pair, query=qry, context=ctx)
+        eps = model.apply_model(x_in, t_in, {"c_crossattn": [ctx], "example_pair": [pair], "query": [qry]})
+        samples, inter = sampler.sample(S, B, (cfg.in_channels, h, w), cond, eta=eta, x_T=tt["x_T"],
+                                        unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc,
+                                        log_every_t=1, verbose=False)
+    res = dict(B=B, h=h, w=w, S=S, cfg_scale=cfg_scale, eta=eta, first_step=step,
+               eps=t2n(eps), x_inter=np.stack([t2n(x) for x in inter["x_inter"]]),
+               pred_x0=np.stack([t2n(x) for x in inter["pred_x0"]]), samples=t2n(samples))
+    for i, c in enumerate(control):
+        c = t2n(c)
+        if c.size <= 70000:
+            res[f"control_{i}"] = c
+        else:
+            sub, stride = subsample(c)
+            res[f"control_{i}_sub"] = sub
+            res[f"control_{i}_stride"] = stride
+        res[f"control_{i}_stats"] = np.array([c.mean(), np.abs(c).mean(), c.std(), np.abs(c).max()], np.float64)
+        res[f"control_{i}_shape"] = np.array(c.shape)
+    np.savez_compressed(os.path.join(out, f"net_{tag}.npz"), **res)
+    print(f"[golden] net_{tag}: eps |mean| {np.abs(res['eps']).mean():.4f}, "
+          f"x_final |mean| {np.abs(res['samples']).mean():.4f}")
+
+
+def run_op_cases(cfg, W, out):
+    """Per-operator fixtures from the reference's own modules."""
+    from ldm.modules.diffusionmodules.openaimodel import ResBlock, Downsample, Upsample
+    from ldm.modules.attention import SpatialTransformer, CrossAttention
+    from ldm.modules.diffusionmodules.util import timestep_embedding
+    g = np.random.Generator(np.random.Philox(key=[77, 1]))
+    res = {}
+    t = np.array([1, 21, 201, 801, 981, 999], dtype=np.int64)
+    res["temb_t"] = t
+    res["temb_320"] = t2n(timestep_embedding(torch.from_numpy(t), 320))
+    res["temb_64"] = t2n(timestep_embedding(torch.from_numpy(t), 64))
+
+    def load(mod, prefix):
+        sd = mod.state_dict()
+        new = {}
+        for k, v in sd.items():
+            kind = "w" if v.ndim > 1 else ("gamma" if ("norm" in k or "layers.0" in k) and k.endswith("weight") else "b")
+            new[k] = torch.from_numpy(W.synth_tensor(prefix + k, v.shape, kind, seed=99))
+            spec.append([prefix + k, list(v.shape), kind])
+        mod.load_state_dict(new)
+        mod.eval()
+
+    spec = []  # [name, shape, kind]: parameters are regenerated from the recipe (seed 99)
+    with torch.no_grad():
+        # ResBlock with channel change (skip conv1x1) and without
+        for tag, cin, cout, hw in (("res_a", 64, 128, 8), ("res_b", 96, 96, 12)):
+            m = ResBlock(cin, 256, 0.0, out_channels=cout, dims=2)
+            load(m, tag + ".")
+            x = g.standard_normal((2, cin, hw, hw), dtype=np.float32)
+            e = g.standard_normal((2, 256), dtype=np.float32)
+            res[tag + "_x"], res[tag + "_emb"] = x, e
+            res[tag + "_y"] = t2n(m(torch.from_numpy(x), torch.from_numpy(e)))
+        # SpatialTransformer dh = 40 (C 320 is too big for a fixture; use C=160 heads 4 -> dh 40), dh = 16
+        for tag, ch, heads, hw, ctxd in (("st_a", 160, 4, 8, 48), ("st_b", 128, 8, 6, 96)):
+            m = SpatialTransformer(ch, heads, ch // heads, depth=1, context_dim=ctxd, use_checkpoint=False)
+            load(m, tag + ".")
+            x = g.standard_normal((2, ch, hw, hw), dtype=np.float32)
+            c = g.standard_normal((2, 77, ctxd), dtype=np.float32)
+            res[tag + "_x"], res[tag + "_ctx"] = x, c
+            res[tag + "_y"] = t2n(m(torch.from_numpy(x), torch.from_numpy(c)))
+        # CrossAttention alone (self and cross)
+        m = CrossAttention(query_dim=80, context_dim=48, heads=2, dim_head=40)
+        load(m, "ca.")
+        x = g.standard_normal((2, 100, 80), dtype=np.float32)
+        c = g.standard_normal((2, 77, 48), dtype=np.float32)
+        res["ca_x"], res["ca_ctx"] = x, c
+        res["ca_y"] = t2n(m(torch.from_numpy(x), torch.from_numpy(c)))
+        m = Downsample(32, True, dims=2)
+        load(m, "down.")
+        x = g.standard_normal((2, 32, 10, 10), dtype=np.float32)
+        res["down_x"], res["down_y"] = x, t2n(m(torch.from_numpy(x)))
+        m = Upsample(32, True, dims=2)
+        load(m, "up.")
+        res["up_y"] = t2n(m(torch.from_numpy(x)))
+    np.savez_compressed(os.path.join(out, "ops.npz"), **res)
+    with open(os.path.join(out, "ops_params.json"), "w") as f:
+        json.dump(spec, f)
+    print("[golden] ops.npz written")
+
+
+def run_schedule_cases(cfg, W, out):
+    model, _, _ = build_reference(W.TINY, W)
+    res = {}
+    for S, eta in ((5, 0.0), (50, 0.0), (20, 0.0), (50, 0.5), (10, 1.0)):
+        s = make_sampler(model)
+        s.make_schedule(S, ddim_eta=eta, verbose=False)
+        tag = f"S{S}_eta{eta}"
+        res[tag + "_timesteps"] = np.asarray(s.ddim_timesteps)
+        # exactly the scalars p_sample_ddim materialises through torch.full (float32)
+        for name in ("ddim_alphas", "ddim_alphas_prev", "ddim_sigmas", "ddim_sqrt_one_minus_alphas"):
+            arr = getattr(s, name)
+            vals = [float(torch.full((1,), arr[i]).item()) for i in range(S)]
+            res[f"{tag}_{name}"] = np.asarray(vals, dtype=np.float32)
+    res["alphas_cumprod"] = t2n(model.alphas_cumprod)
+    np.savez_compressed(os.path.join(out, "schedule.npz"), **res)
+    print("[golden] schedule.npz written")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-sd15", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    install_stubs()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    from prompt_diffusion_amd import weights as W
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    out = HERE
+    only = set(args.only.split(",")) if args.only else None
+
+    def want(k):
+        return only is None or k in only
+    if want("spec"):
+        # names + shapes of the reference's own state dicts, as data
+        from cldm.cldm import ControlNet, ControlledUnetModel
+        kw = ref_kwargs(W.SD15)
+        with torch.device("meta"):
+            cn = ControlNet(hint_channels=6, **kw)
+            un = ControlledUnetModel(out_channels=4, **kw)
+        spec = {"unet": [[k, list(v.shape)] for k, v in un.state_dict().items()],
+                "controlnet": [[k, list(v.shape)] for k, v in cn.state_dict().items()]}
+        with open(os.path.join(out, "state_dict_spec_sd15.json"), "w") as f:
+            json.dump(spec, f)
+        print("[golden] state_dict_spec_sd15.json:", len(spec["unet"]), len(spec["controlnet"]))
+    if want("schedule"):
+        run_schedule_cases(W.SD15, W, out)
+    if want("ops"):
+        run_op_cases(W.TINY, W, out)
+    if want("tiny"):
+        run_net_case("tiny_b2_16x16_s5", W.TINY, W, B=2, h=16, w=16, S=5, cfg_scale=7.5, eta=0.0, out=out)
+        run_net_case("tiny_b1_8x24_s4", W.TINY, W, B=1, h=8, w=24, S=4, cfg_scale=9.0, eta=0.0, out=out)
+    if want("sd15") and not args.skip_sd15:
+        # BASELINE config #1: 256x256 (latent 32x32), 5 DDIM steps, bs=1, CFG
+        run_net_case("sd15_b1_32x32_s5", W.SD15, W, B=1, h=32, w=32, S=5, cfg_scale=7.5, eta=0.0, out=out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+"""The oracle (oracle/pd_oracle.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only.  Tolerances are fp32 round-off of two different
+summation orders (torch/oneDNN vs NumPy/OpenBLAS): 2e-5 relative to the tensor's max."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pd_oracle as O
+from prompt_diffusion_amd import weights as W
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_schedule_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    _, ac = O.register_schedule()
+    np.testing.assert_array_equal(ac, g["alphas_cumprod"])
+    for S, eta in ((5, 0.0), (50, 0.0), (20, 0.0), (50, 0.5), (10, 1.0)):
+        s = O.make_schedule(S, eta)
+        tag = f"S{S}_eta{eta}"
+        np.testing.assert_array_equal(s["ddim_timesteps"], g[tag + "_timesteps"])
+        for k in ("ddim_alphas", "ddim_alphas_prev", "ddim_sigmas", "ddim_sqrt_one_minus_alphas"):
+            np.testing.assert_allclose(s[k], g[f"{tag}_{k}"], rtol=3e-7, atol=0, err_msg=f"{tag} {k}")
+    assert list(O.make_schedule(5)["ddim_timesteps"]) == [1, 201, 401, 601, 801]
+
+
+def test_timestep_embedding(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    for dim in (320, 64):
+        got = O.timestep_embedding(g["temb_t"], dim)
+        # arguments reach 999 rad; a 1-ulp difference in expf (torch vs NumPy) moves cos/sin by <= 999*6e-8
+        np.testing.assert_allclose(got, g[f"temb_{dim}"], atol=1e-4)
+
+
+def _op_params(golden_dir):
+    with open(os.path.join(golden_dir, "ops_params.json")) as f:
+        spec = json.load(f)
+    return {n: W.synth_tensor(n, s, k, seed=99) for n, s, k in spec}
+
+
+def test_ops_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    sd = _op_params(golden_dir)
+    for tag in ("res_a", "res_b"):
+        y = O.resblock(O.Net(sd, tag + "."), "", g[tag + "_x"], g[tag + "_emb"])
+        assert relerr(y, g[tag + "_y"]) < 2e-5, tag
+    for tag, heads in (("st_a", 4), ("st_b", 8)):
+        y = O.spatial_transformer(O.Net(sd, tag + "."), "", g[tag + "_x"], g[tag + "_ctx"], heads)
+        assert relerr(y, g[tag + "_y"]) < 2e-5, tag
+    y = O.cross_attention(O.Net(sd, "ca."), "", g["ca_x"], g["ca_ctx"], heads=2)
+    assert relerr(y, g["ca_y"]) < 2e-5
+    p = O.Net(sd, "down.")
+    assert relerr(O.conv2d(g["down_x"], p("op.weight"), p("op.bias"), stride=2), g["down_y"]) < 2e-5
+    p = O.Net(sd, "up.")
+    up = np.repeat(np.repeat(g["down_x"], 2, axis=2), 2, axis=3)
+    assert relerr(O.conv2d(up, p("conv.weight"), p("conv.bias")), g["up_y"]) < 2e-5
+
+
+def test_param_inventory_matches_reference(golden_dir):
+    with open(os.path.join(golden_dir, "state_dict_spec_sd15.json")) as f:
+        ref = json.load(f)
+    mine_u = [[n[len(W.UNET_PREFIX):], list(s)] for n, s, _ in W.unet_spec(W.SD15)]
+    mine_c = [[n[len(W.CNET_PREFIX):], list(s)] for n, s, _ in W.controlnet_spec(W.SD15)]
+    assert mine_u == ref["unet"]
+    assert mine_c == ref["controlnet"]
+    assert W.num_params(W.SD15) == (859520964, 362366032)   # run_prompt_diffusion.ipynb:70, SURVEY §6
+
+
+def _replay(golden_dir, tag, cfg, steps_limit=None):
+    g = np.load(os.path.join(golden_dir, f"net_{tag}.npz"))
+    B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
+    sd = W.synth_state_dict(cfg)
+    lay = O.make_layouts(cfg, W)
+    inp = W.synth_inputs(cfg, B, h, w)
+    cond = dict(c_crossattn=inp["ctx_cond"], example_pair=inp["pair"], query=inp["query"])
+    unc = dict(c_crossattn=inp["ctx_uncond"], example_pair=inp["pair"], query=inp["query"])
+    return g, sd, lay, inp, cond, unc, (B, h, w, S)
+
+
+@pytest.mark.parametrize("tag", ["tiny_b2_16x16_s5", "tiny_b1_8x24_s4"])
+def test_tiny_network_and_sampler(golden_dir, tag):
+    cfg = W.TINY
+    g, sd, lay, inp, cond, unc, (B, h, w, S) = _replay(golden_dir, tag, cfg)
+    # apply_model on the CFG batch at the first step, plus the 13 control residuals
+    x_in = np.concatenate([inp["x_T"]] * 2)
+    t_in = np.full((2 * B,), int(g["first_step"]), dtype=np.int64)
+    ctx = np.concatenate([inp["ctx_uncond"], inp["ctx_cond"]])
+    pair = np.concatenate([inp["pair"]] * 2)
+    qry = np.concatenate([inp["query"]] * 2)
+    eps, control = O.apply_model(sd, cfg, lay, x_in, t_in, ctx, pair, qry, return_control=True)
+    assert relerr(eps, g["eps"]) < 5e-5
+    for i, c in enumerate(control):
+        assert tuple(c.shape) == tuple(g[f"control_{i}_shape"])
+        if f"control_{i}" in g:
+            assert relerr(c, g[f"control_{i}"]) < 5e-5, i
+        else:
+            st = int(g[f"control_{i}_stride"])
+            sub = c.reshape(-1)[::st][:4096]
+            assert relerr(sub, g[f"control_{i}_sub"]) < 5e-5, i
+    # whole DDIM trajectory (x_inter has S+1 latents, ddim_hacked.py:174-176 with log_every_t=1)
+    _, x_inter, preds = O.ddim_sampling(sd, cfg, lay, S, inp["x_T"], cond, unc, float(g["cfg_scale"]),
+                                        eta=float(g["eta"]))
+    for i in range(S + 1):
+        assert relerr(x_inter[i], g["x_inter"][i]) < 1e-4, i
+        assert relerr(preds[i], g["pred_x0"][i]) < 1e-4, i
+
+
+@pytest.mark.slow
+def test_sd15_config1_first_and_last_step(golden_dir):
+    """BASELINE config #1 (256x256, 5 DDIM steps, bs 1): replay steps 0 and 4 of the reference
+    trajectory, each from the reference's own previous latent."""
+    path = os.path.join(golden_dir, "net_sd15_b1_32x32_s5.npz")
+    if not os.path.exists(path):
+        pytest.skip("sd15 fixture not generated")
+    cfg = W.SD15
+    g, sd, lay, inp, cond, unc, (B, h, w, S) = _replay(golden_dir, "sd15_b1_32x32_s5", cfg)
+    sched = O.make_schedule(S)
+    tr = np.flip(sched["ddim_timesteps"])
+    for i in (0, S - 1):
+        x_prev, pred, _ = O.p_sample_ddim(sd, cfg, lay, sched, g["x_inter"][i], cond, unc, S - i - 1,
+                                          int(tr[i]), float(g["cfg_scale"]))
+        assert relerr(x_prev, g["x_inter"][i + 1]) < 1e-4, i
+        assert relerr(pred, g["pred_x0"][i + 1]) < 1e-4, i
