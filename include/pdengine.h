@@ -1,0 +1,166 @@
+/* pdengine.h -- C ABI of the MI355X-native Prompt-Diffusion DDIM sampling engine.
+ *
+ * This is the drop-in boundary for the reference's hot path: the work the
+ * reference does, per denoising step, inside
+ *     DDIMSampler.sample / ddim_sampling / p_sample_ddim      cldm/ddim_hacked.py:55-234
+ *     ControlLDM.apply_model                                   cldm/cldm.py:369-382
+ *     ControlNet.forward / ControlledUnetModel.forward          cldm/cldm.py:302-325, :23-45
+ * and, under diffusers naming, inside PromptDiffusionPipeline.__call__'s loop
+ *     pipeline_prompt_diffusion.py:1210-1290 + promptdiffusioncontrolnet.py:188-391.
+ *
+ * Plain C: opaque handle, pointers and sizes only; no torch types.  All tensors that cross
+ * the boundary are float32 in the reference's own layouts (NCHW images/latents,
+ * [B, L, D] text context).  Every entry point returns 0 on success, non-zero on error and
+ * never throws; pd_last_error() returns the thread-local message of the last failure.
+ * One engine <-> one GPU <-> one HIP stream; calls on one engine must be serialised by the
+ * caller (the reference pipeline is not thread-safe either, pipeline_prompt_diffusion.py:1065).
+ */
+#ifndef PDENGINE_H
+#define PDENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD_ABI_VERSION 1
+
+/* arithmetic mode of the engine */
+#define PD_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate / norm statistics / softmax */
+#define PD_PREC_F32 1  /* fp32 MFMA (v_mfma_f32_16x16x4_f32): bit-faithful fp32 arithmetic */
+
+/* where caller-owned I/O buffers live */
+#define PD_MEM_HOST 0
+#define PD_MEM_DEVICE 1
+
+/* dtype tags for pd_load_weights */
+#define PD_DT_F32 0
+#define PD_DT_F16 1
+#define PD_DT_BF16 2
+
+#define PD_MAX_LEVELS 8
+#define PD_NUM_CONTROL 13 /* 12 input blocks + middle, cldm/cldm.py:313-323 */
+
+typedef struct pd_engine pd_engine;
+
+/* Hyper-parameters = models/cldm_v15.yaml:30-62 (ControlNet and UNet share them). */
+typedef struct pd_config {
+    int32_t in_channels;      /* 4 */
+    int32_t out_channels;     /* 4 */
+    int32_t hint_channels;    /* 6: example pair, cldm/cldm.py:147 */
+    int32_t query_channels;   /* 3: query image, cldm/cldm.py:166 */
+    int32_t model_channels;   /* 320 */
+    int32_t num_levels;       /* 4 */
+    int32_t channel_mult[PD_MAX_LEVELS]; /* 1,2,4,4 */
+    int32_t num_res_blocks;   /* 2 */
+    int32_t num_attn_res;     /* 3 */
+    int32_t attention_resolutions[PD_MAX_LEVELS]; /* 4,2,1 */
+    int32_t num_heads;        /* 8 */
+    int32_t context_dim;      /* 768 */
+    int32_t context_len;      /* 77 */
+    int32_t hint_widths[7];   /* 16,16,32,32,96,96,256: cldm/cldm.py:147-163 */
+    int32_t timesteps;        /* 1000 */
+    double linear_start;      /* 0.00085 (double: the schedule is derived in float64, util.py:22-25) */
+    double linear_end;        /* 0.0120 */
+    int32_t precision;        /* PD_PREC_* */
+    int32_t stream_f32;       /* PD_PREC_BF16 only: keep the residual stream (block outputs) in fp32 */
+    int32_t reserved[6];
+} pd_config;
+
+/* Arguments of one sampling call (replaces DDIMSampler.sample's arguments,
+ * cldm/ddim_hacked.py:55-79, and the loop state of PromptDiffusionPipeline.__call__). */
+typedef struct pd_sample_args {
+    int32_t batch;            /* B images; the engine runs the CFG-doubled batch 2B when use_cfg */
+    int32_t h, w;             /* latent height/width = image/8 */
+    int32_t steps;            /* S */
+    float eta;                /* ddim eta */
+    float cfg_scale;          /* unconditional_guidance_scale / guidance_scale */
+    int32_t use_cfg;          /* (L): unconditional_conditioning is not None, ddim_hacked.py:188;
+                                 (D): guidance_scale > 1, pipeline_prompt_diffusion.py:878 */
+    int32_t guess_mode;       /* (D) :1220-1224,:1248-1253: ControlNet sees the cond half only */
+    int32_t only_mid_control; /* cldm/cldm.py:38 */
+    float temperature;        /* ddim_hacked.py:230 */
+    int32_t mem;              /* PD_MEM_* of every pointer below */
+    const float* x_T;         /* [B, in_ch, h, w] initial latents (required) */
+    const float* ctx_cond;    /* [B, L, D] */
+    const float* ctx_uncond;  /* [B, L, D] (use_cfg) */
+    const float* pair;        /* [B, hint_ch, 8h, 8w] example pair */
+    const float* query;       /* [B, query_ch, 8h, 8w] query image */
+    const float* pair_uncond; /* optional: unconditional example pair (NULL = same as pair) */
+    const float* query_uncond;/* optional */
+    const float* control_scales;      /* [13] or NULL (= all 1.0), cldm/cldm.py:335,379 */
+    const float* control_scales_step; /* optional [steps][13]: per-step scales in sampling order
+                                         (controlnet_keep gating, pipeline :1196-1202,:1229-1235) */
+    const float* noise;       /* eta > 0: [steps][B, in_ch, h, w] standard normal draws, or NULL */
+    int32_t reserved[8];
+} pd_sample_args;
+
+const char* pd_last_error(void);
+int pd_abi_version(void);
+
+/* lifecycle (replaces create_model + load_state_dict + .to(device), cldm/model.py:12-28) */
+int pd_engine_create(const pd_config* cfg, int device_id, pd_engine** out);
+void pd_engine_destroy(pd_engine* e);
+
+/* parameter registry: names/shapes are the reference checkpoint's (model.diffusion_model.*,
+ * control_model.*; tool_add_control.py:36-45) */
+int pd_param_count(pd_engine* e);
+int pd_param_info(pd_engine* e, int index, const char** name, int32_t* ndim, int64_t shape[4]);
+/* copy one tensor from HOST memory; the engine repacks it (NHWC taps, bf16, fused QKV). */
+int pd_load_weights(pd_engine* e, const char* name, const void* data, const int64_t* shape,
+                    int32_t ndim, int32_t dtype);
+/* device-side seeded N(0, 1/fan_in)-style initialisation of every tensor (benchmarks only) */
+int pd_init_random_weights(pd_engine* e, uint64_t seed);
+/* number of tensors not loaded yet (0 = ready) */
+int pd_weights_missing(pd_engine* e);
+
+/* operator boundary: eps = apply_model(x, t, cond), cldm/cldm.py:369-382.
+ *   x [Bf,in_ch,h,w], t [Bf] (int64), ctx [Bf,L,D], pair [Bf,hint_ch,8h,8w], query [Bf,q_ch,8h,8w],
+ *   scales [13] or NULL.  eps_out [Bf,out_ch,h,w].  residuals_out (optional): the 13 scaled
+ *   control tensors, NCHW, concatenated in list order (sizes from pd_control_shape). */
+int pd_eps(pd_engine* e, const float* x, const int64_t* t, const float* ctx, const float* pair,
+           const float* query, const float* scales, int32_t Bf, int32_t h, int32_t w, int32_t mem,
+           float* eps_out, float* residuals_out);
+int pd_control_shape(pd_engine* e, int index, int32_t h, int32_t w, int32_t* C, int32_t* H, int32_t* W);
+
+/* the fused loop: begin + S steps + read-back; blocking (stream-synchronised on return).
+ *   latents_out [B,in_ch,h,w]; per_step_out optional [S+1][B,in_ch,h,w] = x_inter incl. x_T
+ *   (intermediates with log_every_t=1, ddim_hacked.py:143,174-176). */
+int pd_ddim_sample(pd_engine* e, const pd_sample_args* args, int32_t mem_out, float* latents_out,
+                   float* per_step_out);
+
+/* stepwise form, for callbacks that inspect or replace latents between steps
+ * (callback/img_callback ddim_hacked.py:171-172; callback_on_step_end pipeline :1275-1283) */
+int pd_sample_begin(pd_engine* e, const pd_sample_args* args);
+int pd_sample_step(pd_engine* e, int32_t i); /* i = 0..steps-1, asynchronous on the engine stream */
+#define PD_GET_LATENTS 0
+#define PD_GET_PRED_X0 1
+#define PD_GET_EPS 2 /* guided noise prediction of the last step */
+int pd_sample_get(pd_engine* e, int32_t what, int32_t mem, float* out);
+int pd_sample_set_latents(pd_engine* e, int32_t mem, const float* latents);
+/* guided eps at an arbitrary timestep for the current latents, no update: lets a host-side
+ * scheduler (pipeline :1273 scheduler.step) drive the engine */
+int pd_sample_eps_at(pd_engine* e, int64_t t, const float* scales13);
+int pd_sample_end(pd_engine* e);
+
+/* schedule exactly as DDIMSampler.make_schedule derives it (cldm/ddim_hacked.py:23-52):
+ * fills timesteps[S] (ascending), alphas[S], alphas_prev[S], sigmas[S], sqrt_one_minus_alphas[S] */
+int pd_make_schedule(pd_engine* e, int32_t steps, float eta, int64_t* timesteps, float* alphas,
+                     float* alphas_prev, float* sigmas, float* sqrt_one_minus_alphas);
+
+/* instrumentation */
+int pd_synchronize(pd_engine* e);
+void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches on */
+int pd_set_option(pd_engine* e, const char* key, int64_t value); /* "use_graph", "verbose" ... */
+int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches_per_step" */
+/* Micro-benchmark hook used by bench.py's roofline leg: times `iters` launches of the dominant
+ * conv3x3 implicit-GEMM kernel (Cin->Cout at HxW, batch Bf) with HIP events on the engine
+ * stream; returns average ms per launch in *ms. */
+int pd_bench_conv3x3(pd_engine* e, int32_t Bf, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                     int32_t iters, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDENGINE_H */

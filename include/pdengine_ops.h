@@ -1,0 +1,28 @@
+/* pdengine_ops.h -- per-operator parity hooks of libpdengine.so (test surface, not the product path).
+ *
+ * Each hook runs exactly one kernel family of the hot path on host fp32 arrays in the reference's
+ * layouts, in the engine's precision mode, so tests/ can compare it with the oracle:
+ *   pd_op_conv2d     nn.Conv2d 3x3/1x1 (stride 1/2, fused nearest-x2 upsample)   openaimodel.py:90-159,200-240
+ *   pd_op_linear     nn.Linear / GEGLU / SiLU->Linear (emb_layers)                 attention.py:49-76, openaimodel.py:217-223
+ *   pd_op_groupnorm  GroupNorm32 (+SiLU)                                           util.py:217-219, attention.py:88-89
+ *   pd_op_layernorm  nn.LayerNorm                                                  attention.py:263-265
+ *   pd_op_attention  softmax(q k^T dh^-0.5) v, heads from the engine config        attention.py:171-193
+ */
+#ifndef PDENGINE_OPS_H
+#define PDENGINE_OPS_H
+#include "pdengine.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int pd_op_conv2d(pd_engine* e, const float* x, const float* w, const float* bias, const float* residual, int B, int Cin, int H,
+                 int W, int Cout, int k, int stride, int upsample, int act_silu, float scale, int stream_out, float* y);
+int pd_op_linear(pd_engine* e, const float* x, const float* w, const float* bias, int M, int K, int N, int geglu, int a_silu,
+                 float* y);
+int pd_op_groupnorm(pd_engine* e, const float* x, const float* gamma, const float* beta, int B, int C, int H, int W, float eps,
+                    int silu, float* y);
+int pd_op_layernorm(pd_engine* e, const float* x, const float* gamma, const float* beta, int rows, int C, float* y);
+int pd_op_attention(pd_engine* e, const float* q, const float* k, const float* v, int B, int Nq, int Nk, int C, float* o);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,262 @@
+// Fused (flash-style) attention for gfx950: softmax(Q K^T * dh^-0.5) V without materialising the
+// [N,N] score matrix the reference builds (ldm/modules/attention.py:171-193).  fp32 logits, fp32
+// online softmax (the reference forces fp32 logits, attention.py:173-177).
+//
+// Layouts: Q [B, Nq, heads*dh] and K [B, Nk, heads*dh] token-major (they are column slices of the
+// fused QKV / KV projection outputs); V arrives TRANSPOSED, VT [B, heads*dh, Nk_pad], written that
+// way by the projection GEMM's epilogue so every query block can stage it with 16-byte loads.
+// Block = 4 waves = 128 queries of one (sample, head); each wave owns 32 queries; K / V^T tiles of 64
+// keys are staged in LDS and shared by the 4 waves.
+// Both products are issued "swapped" so that the query index lives on the MFMA lane (column) axis:
+//   S^T[key, query] = K . Q^T            (A = K rows from LDS, B = Q rows kept in registers)
+//   O^T[d,   query] = V^T . P^T          (A = V^T rows from LDS, B = P^T straight from S^T's registers)
+// The S^T accumulator of a 16-key tile holds keys 4*(lane>>4)+j for query lane&15, which is exactly the
+// k-slot the next MFMA's B operand wants (k order permuted identically on the V^T read), so P never
+// goes through LDS, softmax row statistics are lane-local plus two cross-lane steps (xor 16, 32), and
+// the O^T rescale uses the lane's own alpha.
+#include "pd_common.h"
+
+namespace {
+
+constexpr int TK = 64;  // keys per tile
+
+template <bool F32>
+__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc) {
+    if constexpr (F32) {
+        const float* af = reinterpret_cast<const float*>(&a);
+        const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    }
+}
+
+template <bool F32, int DH>
+struct AttnCfg {
+    static constexpr int EB = F32 ? 4 : 2;
+    static constexpr int VEC = 16 / EB;
+    static constexpr int NCH = DH * EB / 16;      // 16-byte chunks per head row
+    static constexpr int KS = (NCH + 3) / 4;      // k-steps (4 chunks each) of the QK^T product
+    static constexpr int NTD = (DH + 15) / 16;    // 16-wide d tiles of the output
+    static constexpr int KROW = KS * 64 + 16;     // K tile row stride (odd multiple of 16 B: conflict-free b128 reads)
+    static constexpr int VROW = TK * EB + 16;     // V^T tile row stride
+    static constexpr int VCH = TK * EB / 16;      // chunks per V^T row
+    static constexpr int SMEM = TK * KROW + NTD * 16 * VROW;
+    static_assert((DH * EB) % 16 == 0, "head dim must fill whole 16-byte chunks");
+};
+
+template <bool F32, int DH>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    using Cfg = AttnCfg<F32, DH>;
+    constexpr int EB = Cfg::EB, VEC = Cfg::VEC, NCH = Cfg::NCH, KS = Cfg::KS, NTD = Cfg::NTD;
+    constexpr int KROW = Cfg::KROW, VROW = Cfg::VROW, VCH = Cfg::VCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + TK * KROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int bh = blockIdx.y;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const char* Qb = reinterpret_cast<const char*>(p.Q) + ((size_t)b * p.q_bs + (size_t)h * DH) * EB;
+    const char* Kb = reinterpret_cast<const char*>(p.K) + ((size_t)b * p.k_bs + (size_t)h * DH) * EB;
+    const char* Vb = reinterpret_cast<const char*>(p.VT) + ((size_t)b * p.vt_bs + (size_t)h * DH * p.vt_ld) * EB;
+
+    // Q^T fragments (B operand): lane holds query (lane&15), k = chunk*VEC..
+    uint4 qf[KS][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = q0 + qt * 16 + fr;
+        q = q < p.Nq ? q : p.Nq - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 4 + fq;
+            qf[ks][qt] = c < NCH ? *reinterpret_cast<const uint4*>(Qb + (size_t)q * p.ldq * EB + c * 16) : make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    f32x4 o[NTD][2];
+#pragma unroll
+    for (int n = 0; n < NTD; ++n) { o[n][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[n][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float mrow[2] = {-INFINITY, -INFINITY};
+    float lrow[2] = {0.f, 0.f};
+    const float sl2 = p.scale * 1.4426950408889634f;
+
+    for (int t0 = 0; t0 < p.Nk; t0 += TK) {
+        __syncthreads();
+        // ---- stage K tile [64 keys][KS*4 chunks]
+        for (int idx = tid; idx < TK * KS * 4; idx += 256) {
+            const int r = idx / (KS * 4), c = idx - r * (KS * 4);
+            const int key = t0 + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < NCH && key < p.Nk) v = *reinterpret_cast<const uint4*>(Kb + (size_t)key * p.ldk * EB + c * 16);
+            *reinterpret_cast<uint4*>(sK + r * KROW + c * 16) = v;
+        }
+        // ---- stage V^T tile [NTD*16 d][64 keys]
+        const bool ragged = t0 + TK > p.Nk;
+        for (int idx = tid; idx < NTD * 16 * VCH; idx += 256) {
+            const int d = idx / VCH, c = idx - d * VCH;
+            const int key = t0 + c * VEC;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (d < DH && key < p.Nk) {
+                v = *reinterpret_cast<const uint4*>(Vb + ((size_t)d * p.vt_ld + key) * EB);
+                if (ragged && key + VEC > p.Nk) {  // zero the pad keys inside the chunk (0 * garbage must stay 0)
+                    if constexpr (F32) {
+                        uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (key + j >= p.Nk) w[j] = 0;
+                    } else {
+                        uint16_t* w = reinterpret_cast<uint16_t*>(&v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (key + j >= p.Nk) w[j] = 0;
+                    }
+                }
+            }
+            *reinterpret_cast<uint4*>(sV + d * VROW + c * 16) = v;
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T : 4 key tiles x 2 query tiles
+        f32x4 s[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 kf[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) kf[kt] = *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * KROW + (ks * 4 + fq) * 16);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                mma16<F32>(kf[kt], qf[ks][0], s[kt][0]);
+                mma16<F32>(kf[kt], qf[ks][1], s[kt][1]);
+            }
+        }
+        // ---- online softmax (base-2), query = lane&15 of each query tile
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int key = t0 + kt * 16 + fq * 4 + j;
+                    float v = s[kt][qt][j] * sl2;
+                    v = key < p.Nk ? v : -INFINITY;
+                    s[kt][qt][j] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrow[qt], mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);
+            mrow[qt] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = __builtin_amdgcn_exp2f(s[kt][qt][j] - mnew);
+                    s[kt][qt][j] = e;
+                    ps += e;
+                }
+            lrow[qt] = lrow[qt] * alpha + ps;
+#pragma unroll
+            for (int n = 0; n < NTD; ++n) o[n][qt] *= alpha;
+        }
+        // ---- O^T += V^T P^T
+        if constexpr (F32) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                uint4 pf[2];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) pf[qt] = __builtin_bit_cast(uint4, s[kt][qt]);
+#pragma unroll
+                for (int n = 0; n < NTD; ++n) {
+                    const uint4 vf = *reinterpret_cast<const uint4*>(sV + (n * 16 + fr) * VROW + (kt * 16 + fq * 4) * 4);
+                    mma16<true>(vf, pf[0], o[n][0]);
+                    mma16<true>(vf, pf[1], o[n][1]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                uint4 pf[2];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    pf[qt].x = pack2bf(s[2 * u][qt][0], s[2 * u][qt][1]);
+                    pf[qt].y = pack2bf(s[2 * u][qt][2], s[2 * u][qt][3]);
+                    pf[qt].z = pack2bf(s[2 * u + 1][qt][0], s[2 * u + 1][qt][1]);
+                    pf[qt].w = pack2bf(s[2 * u + 1][qt][2], s[2 * u + 1][qt][3]);
+                }
+#pragma unroll
+                for (int n = 0; n < NTD; ++n) {
+                    const char* row = sV + (n * 16 + fr) * VROW;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(row + ((2 * u) * 16 + fq * 4) * 2);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(row + ((2 * u + 1) * 16 + fq * 4) * 2);
+                    const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    mma16<false>(vf, pf[0], o[n][0]);
+                    mma16<false>(vf, pf[1], o[n][1]);
+                }
+            }
+        }
+    }
+
+    // ---- normalise and store: lane holds d = n*16 + 4*fq + j of query (lane&15)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lrow[qt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q0 + qt * 16 + fr;
+        if (q >= p.Nq) continue;
+#pragma unroll
+        for (int n = 0; n < NTD; ++n) {
+            const int d = n * 16 + fq * 4;
+            if (d >= DH) continue;
+            f32x4 v = o[n][qt] * inv;
+            store4(p.O, (size_t)b * p.o_bs + (size_t)q * p.ldo + (size_t)h * DH + d, F32 ? DT_F32 : DT_BF16, v);
+        }
+    }
+}
+
+template <bool F32, int DH>
+int launch_dh(const AttnParams& p, hipStream_t s) {
+    using Cfg = AttnCfg<F32, DH>;
+    static bool attr_done = false;
+    auto kfn = attn_kernel<F32, DH>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Cfg::SMEM) != hipSuccess)
+            return 1;
+        attr_done = true;
+    }
+    dim3 grid((p.Nq + 127) / 128, p.B * p.heads);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), Cfg::SMEM, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+template <bool F32>
+int launch_prec(const AttnParams& p, hipStream_t s) {
+    switch (p.dh) {
+        case 8: return launch_dh<F32, 8>(p, s);
+        case 16: return launch_dh<F32, 16>(p, s);
+        case 32: return launch_dh<F32, 32>(p, s);
+        case 40: return launch_dh<F32, 40>(p, s);
+        case 64: return launch_dh<F32, 64>(p, s);
+        case 80: return launch_dh<F32, 80>(p, s);
+        case 160: return launch_dh<F32, 160>(p, s);
+        default: return 2;
+    }
+}
+
+}  // namespace
+
+int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s) {
+    if (p.Nq <= 0 || p.Nk <= 0) return 0;
+    return f32mode ? launch_prec<true>(p, s) : launch_prec<false>(p, s);
+}

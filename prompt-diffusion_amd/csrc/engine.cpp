@@ -1,0 +1,760 @@
+// pdengine: network construction, weight loading and the forward pass (host orchestration of the
+// gfx950 kernels).  Mirrors the topology the reference builds in
+//   ldm/modules/diffusionmodules/openaimodel.py:442-736 (UNetModel.__init__) and
+//   cldm/cldm.py:48-297 (ControlNet.__init__),
+// and the control flow of cldm/cldm.py:23-45 / :302-325 / :369-382.
+#include "engine.h"
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+static thread_local char g_err[1024] = "";
+void pd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* pd_err_buf() { return g_err; }
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------ construction
+void* pd_engine::dmalloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    // the engine stream is non-blocking w.r.t. the null stream: finish the clear before anyone uses p
+    hipMemset(p, 0, bytes);
+    hipDeviceSynchronize();
+    owned.push_back(p);
+    weight_bytes += bytes;
+    return p;
+}
+
+void pd_engine::make_mat(WMat& m, int n_rows, int k_in, int taps, int cin, bool bias, bool geglu) {
+    const int EB = (int)dt_size(T);
+    const int BKE = 128 / EB;
+    m.taps = taps;
+    m.cin = cin;
+    m.cin_pad = round_up(cin, 8);
+    m.K = taps * m.cin_pad;
+    m.Kpad = round_up(m.K, BKE);
+    m.geglu = geglu;
+    m.fan_in = k_in;
+    if (geglu) {
+        const int half = n_rows / 2;
+        m.N = (half + 79) / 80 * 160;
+        m.Nout = half;
+    } else {
+        m.N = round_up(n_rows, 4);
+        m.Nout = n_rows;
+    }
+    m.w = dmalloc((size_t)m.N * m.Kpad * EB);
+    m.bias = bias ? reinterpret_cast<float*>(dmalloc((size_t)(m.N + 4) * sizeof(float))) : nullptr;
+}
+
+void pd_engine::reg_mat(const std::string& name, std::vector<int64_t> shape, WMat* m, int row_off, bool conv) {
+    Param p;
+    p.name = name;
+    p.shape = std::move(shape);
+    p.kind = 1;
+    p.mat = m;
+    p.row_off = row_off;
+    p.conv = conv;
+    p.init = 'w';
+    index[name] = (int)params.size();
+    params.push_back(std::move(p));
+}
+
+void pd_engine::reg_vec(const std::string& name, int n, float** dst, char init) {
+    *dst = reinterpret_cast<float*>(dmalloc((size_t)(n + 4) * sizeof(float)));
+    Param p;
+    p.name = name;
+    p.shape = {n};
+    p.kind = 0;
+    p.vdst = *dst;
+    p.init = init;
+    index[name] = (int)params.size();
+    params.push_back(std::move(p));
+}
+
+void pd_engine::reg_bias(const std::string& name, WMat* m, int off, int n, bool geglu) {
+    Param p;
+    p.name = name;
+    p.shape = {n};
+    p.kind = 0;
+    p.vdst = m->bias + off;
+    p.geglu_vec = geglu;
+    p.geglu_half = geglu ? n / 2 : 0;
+    p.init = 'b';
+    index[name] = (int)params.size();
+    params.push_back(std::move(p));
+}
+
+void pd_engine::build_conv(const std::string& prefix, ConvW& c, int cin, int cout, int k, int stride) {
+    c.cin = cin;
+    c.cout = cout;
+    c.k = k;
+    c.stride = stride;
+    make_mat(c.m, cout, cin * k * k, k * k, cin, true);
+    reg_mat(prefix + "weight", {cout, cin, k, k}, &c.m, 0, true);
+    reg_bias(prefix + "bias", &c.m, 0, cout);
+}
+
+void pd_engine::build_res(const std::string& prefix, ResW& r, int cin, int cout, NetW& net) {
+    const int temb = cfg.model_channels * 4;
+    r.cin = cin;
+    r.cout = cout;
+    reg_vec(prefix + "in_layers.0.weight", cin, &r.gn1_g, 'g');
+    reg_vec(prefix + "in_layers.0.bias", cin, &r.gn1_b, 'e');
+    build_conv(prefix + "in_layers.2.", r.conv1, cin, cout, 3, 1);
+    make_mat(r.emb, cout, temb, 1, temb, true);
+    reg_mat(prefix + "emb_layers.1.weight", {cout, temb}, &r.emb, 0, false);
+    reg_bias(prefix + "emb_layers.1.bias", &r.emb, 0, cout);
+    reg_vec(prefix + "out_layers.0.weight", cout, &r.gn2_g, 'g');
+    reg_vec(prefix + "out_layers.0.bias", cout, &r.gn2_b, 'e');
+    build_conv(prefix + "out_layers.3.", r.conv2, cout, cout, 3, 1);
+    r.has_skip = cin != cout;
+    if (r.has_skip) build_conv(prefix + "skip_connection.", r.skip, cin, cout, 1, 1);
+    r.emb_slot = net.n_emb++;
+    net.res_list.push_back(&r);
+}
+
+void pd_engine::build_st(const std::string& prefix, STW& s, int ch, NetW& net) {
+    const int ctx = cfg.context_dim;
+    s.C = ch;
+    reg_vec(prefix + "norm.weight", ch, &s.gn_g, 'g');
+    reg_vec(prefix + "norm.bias", ch, &s.gn_b, 'e');
+    build_conv(prefix + "proj_in.", s.proj_in, ch, ch, 1, 1);
+    const std::string t = prefix + "transformer_blocks.0.";
+    make_mat(s.qkv, 3 * ch, ch, 1, ch, false);
+    reg_mat(t + "attn1.to_q.weight", {ch, ch}, &s.qkv, 0, false);
+    reg_mat(t + "attn1.to_k.weight", {ch, ch}, &s.qkv, ch, false);
+    reg_mat(t + "attn1.to_v.weight", {ch, ch}, &s.qkv, 2 * ch, false);
+    make_mat(s.out1, ch, ch, 1, ch, true);
+    reg_mat(t + "attn1.to_out.0.weight", {ch, ch}, &s.out1, 0, false);
+    reg_bias(t + "attn1.to_out.0.bias", &s.out1, 0, ch);
+    make_mat(s.ff1, 8 * ch, ch, 1, ch, true, true);
+    reg_mat(t + "ff.net.0.proj.weight", {8 * ch, ch}, &s.ff1, 0, false);
+    reg_bias(t + "ff.net.0.proj.bias", &s.ff1, 0, 8 * ch, true);
+    make_mat(s.ff2, ch, 4 * ch, 1, 4 * ch, true);
+    reg_mat(t + "ff.net.2.weight", {ch, 4 * ch}, &s.ff2, 0, false);
+    reg_bias(t + "ff.net.2.bias", &s.ff2, 0, ch);
+    make_mat(s.q2, ch, ch, 1, ch, false);
+    reg_mat(t + "attn2.to_q.weight", {ch, ch}, &s.q2, 0, false);
+    make_mat(s.kv2, 2 * ch, ctx, 1, ctx, false);
+    reg_mat(t + "attn2.to_k.weight", {ch, ctx}, &s.kv2, 0, false);
+    reg_mat(t + "attn2.to_v.weight", {ch, ctx}, &s.kv2, ch, false);
+    make_mat(s.out2, ch, ch, 1, ch, true);
+    reg_mat(t + "attn2.to_out.0.weight", {ch, ch}, &s.out2, 0, false);
+    reg_bias(t + "attn2.to_out.0.bias", &s.out2, 0, ch);
+    for (int i = 0; i < 3; ++i) {
+        const std::string n = t + "norm" + std::to_string(i + 1);
+        reg_vec(n + ".weight", ch, &s.ln_g[i], 'g');
+        reg_vec(n + ".bias", ch, &s.ln_b[i], 'e');
+    }
+    build_conv(prefix + "proj_out.", s.proj_out, ch, ch, 1, 1);
+    s.kv_slot = net.n_kv++;
+    net.st_list.push_back(&s);
+}
+
+static bool has_attn(const pd_config& c, int ds) {
+    for (int i = 0; i < c.num_attn_res; ++i)
+        if (c.attention_resolutions[i] == ds) return true;
+    return false;
+}
+
+void pd_engine::build_encoder(const std::string& prefix, NetW& net) {
+    const int mc = cfg.model_channels, temb = mc * 4;
+    make_mat(net.te0, temb, mc, 1, mc, true);
+    reg_mat(prefix + "time_embed.0.weight", {temb, mc}, &net.te0, 0, false);
+    reg_bias(prefix + "time_embed.0.bias", &net.te0, 0, temb);
+    make_mat(net.te2, temb, temb, 1, temb, true);
+    reg_mat(prefix + "time_embed.2.weight", {temb, temb}, &net.te2, 0, false);
+    reg_bias(prefix + "time_embed.2.bias", &net.te2, 0, temb);
+    const int nblocks = 1 + cfg.num_levels * cfg.num_res_blocks + (cfg.num_levels - 1);
+    net.enc.resize(nblocks);  // never resized again: ResW/STW addresses are recorded
+    int bi = 0;
+    {
+        EncBlock& b = net.enc[bi];
+        b.kind = 0;
+        b.cout = mc;
+        b.ds = 1;
+        build_conv(prefix + "input_blocks.0.0.", b.conv, cfg.in_channels, mc, 3, 1);
+        ++bi;
+    }
+    int ch = mc, ds = 1;
+    for (int level = 0; level < cfg.num_levels; ++level) {
+        const int mult = cfg.channel_mult[level];
+        for (int nr = 0; nr < cfg.num_res_blocks; ++nr) {
+            EncBlock& b = net.enc[bi];
+            const std::string p = prefix + "input_blocks." + std::to_string(bi) + ".";
+            b.kind = 1;
+            b.cout = mult * mc;
+            b.ds = ds;
+            build_res(p + "0.", b.res, ch, mult * mc, net);
+            ch = mult * mc;
+            b.attn = has_attn(cfg, ds);
+            if (b.attn) build_st(p + "1.", b.st, ch, net);
+            ++bi;
+        }
+        if (level != cfg.num_levels - 1) {
+            EncBlock& b = net.enc[bi];
+            b.kind = 2;
+            b.cout = ch;
+            b.ds = ds;
+            build_conv(prefix + "input_blocks." + std::to_string(bi) + ".0.op.", b.conv, ch, ch, 3, 2);
+            ds *= 2;
+            ++bi;
+        }
+    }
+}
+
+void pd_engine::build_middle(const std::string& prefix, NetW& net) {
+    const int ch = cfg.model_channels * cfg.channel_mult[cfg.num_levels - 1];
+    build_res(prefix + "middle_block.0.", net.mid0, ch, ch, net);
+    build_st(prefix + "middle_block.1.", net.mid1, ch, net);
+    build_res(prefix + "middle_block.2.", net.mid2, ch, ch, net);
+}
+
+int pd_engine::build() {
+    f32 = cfg.precision == PD_PREC_F32;
+    T = f32 ? DT_F32 : DT_BF16;
+    S = (f32 || cfg.stream_f32) ? DT_F32 : DT_BF16;
+    if (cfg.model_channels % 32 || cfg.num_levels < 1 || cfg.num_levels > PD_MAX_LEVELS || cfg.num_heads < 1) {
+        pd_set_error("unsupported config: model_channels must be a multiple of 32, 1..%d levels", PD_MAX_LEVELS);
+        return 1;
+    }
+    const int mc = cfg.model_channels;
+    // ---- UNet (model.diffusion_model.*)
+    {
+        const std::string P = "model.diffusion_model.";
+        NetW& n = unet;
+        build_encoder(P, n);
+        build_middle(P, n);
+        std::vector<int> chans;
+        for (auto& b : n.enc) chans.push_back(b.cout);
+        int ch = chans.back();
+        int ds = 1 << (cfg.num_levels - 1);
+        n.dec.resize(cfg.num_levels * (cfg.num_res_blocks + 1));
+        int di = 0;
+        for (int level = cfg.num_levels - 1; level >= 0; --level) {
+            const int mult = cfg.channel_mult[level];
+            for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+                DecBlock& b = n.dec[di];
+                const std::string p = P + "output_blocks." + std::to_string(di) + ".";
+                const int ich = chans.back();
+                chans.pop_back();
+                b.skip_c = ich;
+                b.cout = mc * mult;
+                build_res(p + "0.", b.res, ch + ich, mc * mult, n);
+                ch = mc * mult;
+                int j = 1;
+                b.attn = has_attn(cfg, ds);
+                if (b.attn) {
+                    build_st(p + "1.", b.st, ch, n);
+                    j = 2;
+                }
+                if (level && i == cfg.num_res_blocks) {
+                    b.up = true;
+                    build_conv(p + std::to_string(j) + ".conv.", b.upconv, ch, ch, 3, 1);
+                    ds /= 2;
+                }
+                ++di;
+            }
+        }
+        reg_vec(P + "out.0.weight", mc, &n.out_g, 'g');
+        reg_vec(P + "out.0.bias", mc, &n.out_b, 'e');
+        build_conv(P + "out.2.", n.outconv, mc, cfg.out_channels, 3, 1);
+    }
+    // ---- ControlNet (control_model.*)
+    {
+        const std::string P = "control_model.";
+        NetW& n = cnet;
+        build_encoder(P, n);
+        n.zero.resize(n.enc.size());
+        for (size_t i = 0; i < n.enc.size(); ++i)
+            build_conv(P + "zero_convs." + std::to_string(i) + ".0.", n.zero[i], n.enc[i].cout, n.enc[i].cout, 1, 1);
+        const int* w = cfg.hint_widths;
+        for (int which = 0; which < 2; ++which) {
+            const int cin0 = which == 0 ? cfg.hint_channels : cfg.query_channels;
+            const char* nm = which == 0 ? "input_hint_block." : "input_cond_block.";
+            std::vector<ConvW>& chain = which == 0 ? n.hint_pair : n.hint_query;
+            const int ci[8] = {cin0, w[0], w[1], w[2], w[3], w[4], w[5], w[6]};
+            const int co[8] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], mc};
+            const int st[8] = {1, 1, 2, 1, 2, 1, 2, 1};
+            chain.resize(8);
+            for (int l = 0; l < 8; ++l) build_conv(P + nm + std::to_string(2 * l) + ".", chain[l], ci[l], co[l], 3, st[l]);
+        }
+        build_middle(P, n);
+        const int ch = mc * cfg.channel_mult[cfg.num_levels - 1];
+        build_conv(P + "middle_block_out.0.", n.mid_out, ch, ch, 1, 1);
+    }
+    if ((int)cnet.enc.size() + 1 != PD_NUM_CONTROL && verbose)
+        fprintf(stderr, "[pdengine] note: %zu control tensors (reference SD1.5 has 13)\n", cnet.enc.size() + 1);
+    if ((int)cnet.enc.size() + 1 > PD_NUM_CONTROL) {
+        pd_set_error("config yields %zu control tensors; at most %d supported", cnet.enc.size() + 1, PD_NUM_CONTROL);
+        return 1;
+    }
+    gn_partial_cap = 8u << 20;
+    gn_partial = reinterpret_cast<double*>(dmalloc(gn_partial_cap));
+    for (void* p : owned)
+        if (!p) {
+            pd_set_error("hipMalloc failed while building the engine (%zu bytes so far)", weight_bytes);
+            return 1;
+        }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ weights
+static inline uint16_t host_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float host_h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+    uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff, u;
+    if (exp == 0) {
+        if (man == 0) u = sign;
+        else {
+            exp = 127 - 15 + 1;
+            while (!(man & 0x400)) { man <<= 1; --exp; }
+            man &= 0x3ff;
+            u = sign | (exp << 23) | (man << 13);
+        }
+    } else if (exp == 31) u = sign | 0x7f800000u | (man << 13);
+    else u = sign | ((exp - 15 + 127) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int pd_engine::load(const char* name, const void* data, const int64_t* shape, int ndim, int dtype) {
+    auto it = index.find(name);
+    if (it == index.end()) {
+        pd_set_error("pd_load_weights: unknown tensor '%s'", name);
+        return 2;
+    }
+    Param& p = params[it->second];
+    if ((int)p.shape.size() != ndim) {
+        pd_set_error("pd_load_weights: '%s' expects %zu dims, got %d", name, p.shape.size(), ndim);
+        return 3;
+    }
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (p.shape[i] != shape[i]) {
+            pd_set_error("pd_load_weights: '%s' shape mismatch at dim %d: expected %lld, got %lld", name, i,
+                         (long long)p.shape[i], (long long)shape[i]);
+            return 3;
+        }
+        n *= (size_t)shape[i];
+    }
+    std::vector<float> src(n);
+    if (dtype == PD_DT_F32) memcpy(src.data(), data, n * 4);
+    else if (dtype == PD_DT_F16) {
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(data);
+        for (size_t i = 0; i < n; ++i) src[i] = host_h2f(h[i]);
+    } else if (dtype == PD_DT_BF16) {
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(data);
+        for (size_t i = 0; i < n; ++i) {
+            uint32_t u = (uint32_t)h[i] << 16;
+            memcpy(&src[i], &u, 4);
+        }
+    } else {
+        pd_set_error("pd_load_weights: unknown dtype %d", dtype);
+        return 4;
+    }
+    HIP_OK(hipSetDevice(device));
+    if (p.kind == 0) {
+        PD_TRY(upload_vec(p.vdst, src.data(), (int)n, p.geglu_vec, p.geglu_half));
+        p.loaded = true;
+        return 0;
+    }
+    WMat& m = *p.mat;
+    const int rows = (int)shape[0];
+    const int cin = p.conv ? (int)shape[1] : (int)(n / rows);
+    const int kk = p.conv ? (int)(shape[2] * shape[3]) : 1;
+    if (cin != m.cin || kk != m.taps) {
+        pd_set_error("pd_load_weights: '%s' inner shape does not match the layer (cin %d vs %d, taps %d vs %d)", name, cin,
+                     m.cin, kk, m.taps);
+        return 3;
+    }
+    PD_TRY(upload_rows(m, p.row_off, src.data(), rows, p.conv));
+    p.loaded = true;
+    return 0;
+}
+
+int pd_engine::upload_vec(float* dst_dev, const float* src, int n, bool geglu, int half) {
+    if (geglu) {
+        // permute like the weight rows: 80 x-columns then 80 gate-columns per 160-row block
+        const int nb = (half + 79) / 80;
+        std::vector<float> dst((size_t)nb * 160, 0.f);
+        for (int j = 0; j < half; ++j) {
+            dst[(size_t)(j / 80) * 160 + j % 80] = src[j];
+            dst[(size_t)(j / 80) * 160 + 80 + j % 80] = src[half + j];
+        }
+        HIP_OK(hipMemcpy(dst_dev, dst.data(), dst.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        HIP_OK(hipMemcpy(dst_dev, src, (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// src: [rows][cin] (linear) or [rows][cin][taps] (conv, OIHW) fp32 -> device rows [taps][cin_pad] in the compute type
+int pd_engine::upload_rows(WMat& m, int row_off, const float* src, int rows, bool conv) {
+    const int EB = (int)dt_size(T);
+    const int cin = m.cin, kk = conv ? m.taps : 1;
+    std::vector<char> img((size_t)rows * m.Kpad * EB, 0);
+    for (int r = 0; r < rows; ++r) {
+        char* drow = img.data() + (size_t)r * m.Kpad * EB;
+        for (int tp = 0; tp < kk; ++tp)
+            for (int c = 0; c < cin; ++c) {
+                const float v = conv ? src[((size_t)r * cin + c) * kk + tp] : src[(size_t)r * cin + c];
+                const size_t k = (size_t)tp * m.cin_pad + c;
+                if (EB == 4) reinterpret_cast<float*>(drow)[k] = v;
+                else reinterpret_cast<uint16_t*>(drow)[k] = host_f2bf(v);
+            }
+    }
+    const size_t rowb = (size_t)m.Kpad * EB;
+    if (m.geglu) {
+        // destination rows are interleaved in 80 + 80 blocks (x | gate), see gemm.hip
+        const int half = m.Nout;
+        std::vector<char> perm((size_t)m.N * rowb, 0);
+        for (int r = 0; r < rows; ++r) {
+            const int j = r < half ? r : r - half;
+            const size_t drow = (size_t)(j / 80) * 160 + (r < half ? 0 : 80) + j % 80;
+            memcpy(perm.data() + drow * rowb, img.data() + (size_t)r * rowb, rowb);
+        }
+        HIP_OK(hipMemcpy(m.w, perm.data(), perm.size(), hipMemcpyHostToDevice));
+    } else {
+        HIP_OK(hipMemcpy(reinterpret_cast<char*>(m.w) + (size_t)row_off * rowb, img.data(), (size_t)rows * rowb,
+                         hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int pd_engine::init_random(uint64_t seed) {
+    HIP_OK(hipSetDevice(device));
+    uint64_t k = 0;
+    for (Param& p : params) {
+        ++k;
+        const uint64_t sd = seed * 0x9E3779B97F4A7C15ull + k;
+        if (p.kind == 0) {
+            long long n = p.geglu_vec ? ((p.geglu_half + 79) / 80) * 160 : p.shape[0];
+            float scale = 0.02f, shift = 0.f;
+            if (p.init == 'g') { scale = 0.1f; shift = 1.f; }
+            if (p.init == 'e') scale = 0.1f;
+            if (launch_fill_random(p.vdst, DT_F32, n, scale, shift, sd, stream)) return 1;
+        } else {
+            WMat& m = *p.mat;
+            // fill the whole (padded) row block: pad columns only ever multiply zero-padded inputs
+            const long long rows = m.geglu ? m.N : p.shape[0];
+            const float scale = 1.0f / sqrtf((float)m.fan_in);
+            char* dst = reinterpret_cast<char*>(m.w) + (size_t)(m.geglu ? 0 : p.row_off) * m.Kpad * dt_size(T);
+            if (launch_fill_random(dst, T, rows * m.Kpad, scale, 0.f, sd, stream)) return 1;
+        }
+        p.loaded = true;
+    }
+    HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ primitive ops
+Act pd_engine::new_act(int B, int H, int W, int C, int dt) {
+    Act a;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.dt = dt;
+    a.p = arena.alloc(a.bytes());
+    return a;
+}
+
+int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups, int act, float scale, const Act* R,
+                    const float* rowvec, int rowvec_stride, bool a_silu, void* VT, int vt_begin, int vt_ld, int ldc_override) {
+    if (in.C != m.cin_pad) {
+        pd_set_error("gemm: input has %d channels, layer expects %d", in.C, m.cin_pad);
+        return 1;
+    }
+    if (arena.dry) return 0;
+    GemmParams p{};
+    p.A = in.p; p.W = m.w; p.bias = m.bias; p.C = out.p;
+    p.R = R ? R->p : nullptr;
+    p.rowvec = rowvec;
+    p.VT = VT;
+    p.M = (int)out.rows(); p.N = m.N; p.K = m.K; p.Kpad = m.Kpad;
+    p.lda = in.C;
+    p.ldc = ldc_override ? ldc_override : out.C;
+    p.ldr = R ? R->C : 0;
+    p.a_dt = in.dt; p.c_dt = out.dt; p.r_dt = R ? R->dt : DT_F32;
+    p.taps = m.taps; p.Cin = m.cin_pad;
+    p.Hin = in.H; p.Win = in.W; p.Hout = out.H; p.Wout = out.W; p.stride = stride; p.ups = ups;
+    p.rows_per_sample = out.H * out.W;
+    p.rowvec_stride = rowvec_stride;
+    p.act = m.geglu ? 2 : act;
+    p.a_silu = a_silu ? 1 : 0;
+    p.out_scale = scale;
+    p.vt_begin = VT ? vt_begin : INT_MAX;
+    p.vt_ld = vt_ld;
+    p.Nout = m.Nout;
+    p.splitk = 1;
+    if (f32 && in.dt != DT_F32) {
+        pd_set_error("gemm: fp32 mode needs fp32 activations");
+        return 1;
+    }
+    ++launches;
+    if (launch_gemm(p, f32, stream)) {
+        pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return 1;
+    }
+    return 0;
+}
+
+int pd_engine::conv(const ConvW& c, const Act& in, Act& out, int act, float scale, const Act* R, const float* rowvec,
+                    int rowvec_stride, int ups) {
+    return gemm(c.m, in, out, c.stride, ups, act, scale, R, rowvec, rowvec_stride, false, nullptr, 0, 0);
+}
+
+int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu) {
+    if (arena.dry) return 0;
+    const int HW = x.H * x.W;
+    int nchunk = HW / 64;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 64) nchunk = 64;
+    while ((size_t)x.B * nchunk * 32 * 2 * sizeof(double) > gn_partial_cap && nchunk > 1) nchunk /= 2;
+    launches += 2;
+    if (launch_gn_stats(x.p, x.dt, gn_partial, x.B, HW, x.C, 32, nchunk, stream) ||
+        launch_gn_apply(x.p, x.dt, y.p, y.dt, gn_partial, g, b, x.B, HW, x.C, 32, nchunk, eps, silu ? 1 : 0, stream)) {
+        pd_set_error("groupnorm launch failed (C=%d)", x.C);
+        return 1;
+    }
+    return 0;
+}
+
+int pd_engine::layernorm(const Act& x, Act& y, const float* g, const float* b) {
+    if (arena.dry) return 0;
+    ++launches;
+    if (launch_layernorm(x.p, x.dt, y.p, y.dt, g, b, (int)x.rows(), x.C, 1e-5f, stream)) {
+        pd_set_error("layernorm launch failed (C=%d)", x.C);
+        return 1;
+    }
+    return 0;
+}
+
+int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B,
+                         int Nq, int Nk, int C) {
+    if (arena.dry) return 0;
+    AttnParams p{};
+    p.Q = Q; p.K = K; p.VT = VT; p.O = O;
+    p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.vt_ld = vt_ld;
+    p.q_bs = (long long)Nq * ldq;
+    p.k_bs = (long long)Nk * ldk;
+    p.vt_bs = (long long)C * vt_ld;
+    p.o_bs = (long long)Nq * ldo;
+    p.Nq = Nq; p.Nk = Nk; p.heads = cfg.num_heads; p.dh = C / cfg.num_heads;
+    p.scale = (float)(1.0 / std::sqrt((double)p.dh));
+    p.B = B;
+    ++launches;
+    const int r = launch_attention(p, f32, stream);
+    if (r) {
+        pd_set_error(r == 2 ? "attention: unsupported head dim %d" : "attention launch failed (dh %d)", p.dh);
+        return 1;
+    }
+    return 0;
+}
+
+// ResBlock._forward, openaimodel.py:254-274
+int pd_engine::resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride) {
+    out = new_act(x.B, x.H, x.W, r.cout, S);
+    const size_t mk = arena.mark();
+    Act a = new_act(x.B, x.H, x.W, x.C, T);
+    PD_TRY(groupnorm(x, a, r.gn1_g, r.gn1_b, 1e-5f, true));
+    Act h = new_act(x.B, x.H, x.W, r.cout, T);
+    PD_TRY(conv(r.conv1, a, h, 0, 1.f, nullptr, embrow, emb_stride));
+    Act a2 = new_act(x.B, x.H, x.W, r.cout, T);
+    PD_TRY(groupnorm(h, a2, r.gn2_g, r.gn2_b, 1e-5f, true));
+    Act skip = x;
+    if (r.has_skip) {
+        skip = new_act(x.B, x.H, x.W, r.cout, S);
+        PD_TRY(conv(r.skip, x, skip));
+    }
+    PD_TRY(conv(r.conv2, a2, out, 0, 1.f, &skip));
+    arena.release(mk);
+    return 0;
+}
+
+// SpatialTransformer.forward + BasicTransformerBlock._forward, attention.py:321-340, :271-275
+int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv) {
+    const int B = x.B, H = x.H, W = x.W, C = s.C, N = H * W;
+    out = new_act(B, H, W, C, S);
+    const size_t mk = arena.mark();
+    Act a = new_act(B, H, W, C, T);
+    PD_TRY(groupnorm(x, a, s.gn_g, s.gn_b, 1e-6f, false));
+    Act h = new_act(B, H, W, C, S);
+    PD_TRY(conv(s.proj_in, a, h));
+    // self-attention: fused QKV projection; V stored transposed for the attention kernel
+    Act ln = new_act(B, H, W, C, T);
+    PD_TRY(layernorm(h, ln, s.ln_g[0], s.ln_b[0]));
+    Act qk = new_act(B, H, W, 2 * C, T);
+    const int npad = round_up(N, 8);
+    Act vt = new_act(B, C, 1, npad, T);
+    PD_TRY(gemm(s.qkv, ln, qk, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * C, npad));
+    Act att = new_act(B, H, W, C, T);
+    const size_t eb = dt_size(T);
+    PD_TRY(attention(qk.p, 2 * C, reinterpret_cast<char*>(qk.p) + (size_t)C * eb, 2 * C, vt.p, npad, att.p, C, B, N, N, C));
+    Act h1 = new_act(B, H, W, C, S);
+    PD_TRY(gemm(s.out1, att, h1, 1, 0, 0, 1.f, &h, nullptr, 0, false, nullptr, 0, 0));
+    // cross-attention against the hoisted context K / V^T
+    PD_TRY(layernorm(h1, ln, s.ln_g[1], s.ln_b[1]));
+    Act q2 = new_act(B, H, W, C, T);
+    PD_TRY(gemm(s.q2, ln, q2, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
+    const int L = cfg.context_len, lpad = round_up(L, 8);
+    PD_TRY(attention(q2.p, C, kv.K, C, kv.VT, lpad, att.p, C, B, N, L, C));
+    Act h2 = new_act(B, H, W, C, S);
+    PD_TRY(gemm(s.out2, att, h2, 1, 0, 0, 1.f, &h1, nullptr, 0, false, nullptr, 0, 0));
+    // GEGLU feed-forward
+    PD_TRY(layernorm(h2, ln, s.ln_g[2], s.ln_b[2]));
+    Act g = new_act(B, H, W, 4 * C, T);
+    PD_TRY(gemm(s.ff1, ln, g, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
+    Act h3 = new_act(B, H, W, C, S);
+    PD_TRY(gemm(s.ff2, g, h3, 1, 0, 0, 1.f, &h2, nullptr, 0, false, nullptr, 0, 0));
+    PD_TRY(conv(s.proj_out, h3, out, 0, 1.f, &x));
+    arena.release(mk);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ networks
+static const float* emb_ptr(const std::vector<float*>& tabs, const ResW& r, int row) {
+    return tabs[r.emb_slot] + (size_t)row * r.cout;
+}
+
+// ControlNet.forward, cldm/cldm.py:302-325 (hint embedders hoisted into the session: they do not
+// depend on the timestep); outputs go to ses.control[] already multiplied by control_scales (:379).
+int pd_engine::run_controlnet(const Act& x_in, int emb_row, int emb_stride, const float* scales) {
+    NetW& n = cnet;
+    Act h;
+    for (size_t i = 0; i < n.enc.size(); ++i) {
+        EncBlock& b = n.enc[i];
+        Act o;
+        if (b.kind == 0) {
+            o = new_act(x_in.B, x_in.H, x_in.W, b.cout, S);
+            PD_TRY(conv(b.conv, x_in, o, 0, 1.f, &ses.hint));  // h = conv_in(x) + guided_hint, :315-317
+        } else if (b.kind == 2) {
+            o = new_act(h.B, h.H / 2, h.W / 2, b.cout, S);
+            PD_TRY(conv(b.conv, h, o));
+        } else {
+            PD_TRY(resblock(b.res, h, o, emb_ptr(ses.emb_c, b.res, emb_row), emb_stride ? b.res.cout : 0));
+            if (b.attn) {
+                Act o2;
+                PD_TRY(transformer(b.st, o, o2, ses.kv_c[b.st.kv_slot]));
+                o = o2;
+            }
+        }
+        h = o;
+        PD_TRY(conv(n.zero[i], h, ses.control[i], 0, scales ? scales[i] : 1.f));
+    }
+    Act m0, m1, m2;
+    PD_TRY(resblock(n.mid0, h, m0, emb_ptr(ses.emb_c, n.mid0, emb_row), emb_stride ? n.mid0.cout : 0));
+    PD_TRY(transformer(n.mid1, m0, m1, ses.kv_c[n.mid1.kv_slot]));
+    PD_TRY(resblock(n.mid2, m1, m2, emb_ptr(ses.emb_c, n.mid2, emb_row), emb_stride ? n.mid2.cout : 0));
+    const int last = (int)n.enc.size();
+    PD_TRY(conv(n.mid_out, m2, ses.control[last], 0, scales ? scales[last] : 1.f));
+    return 0;
+}
+
+// ControlledUnetModel.forward, cldm/cldm.py:23-45
+int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_mid, Act& eps) {
+    NetW& n = unet;
+    std::vector<Act> hs;
+    Act h;
+    for (size_t i = 0; i < n.enc.size(); ++i) {
+        EncBlock& b = n.enc[i];
+        Act o;
+        if (b.kind == 0) {
+            o = new_act(x_in.B, x_in.H, x_in.W, b.cout, S);
+            PD_TRY(conv(b.conv, x_in, o));
+        } else if (b.kind == 2) {
+            o = new_act(h.B, h.H / 2, h.W / 2, b.cout, S);
+            PD_TRY(conv(b.conv, h, o));
+        } else {
+            PD_TRY(resblock(b.res, h, o, emb_ptr(ses.emb_u, b.res, emb_row), emb_stride ? b.res.cout : 0));
+            if (b.attn) {
+                Act o2;
+                PD_TRY(transformer(b.st, o, o2, ses.kv_u[b.st.kv_slot]));
+                o = o2;
+            }
+        }
+        h = o;
+        hs.push_back(h);
+    }
+    Act m0, m1, m2;
+    PD_TRY(resblock(n.mid0, h, m0, emb_ptr(ses.emb_u, n.mid0, emb_row), emb_stride ? n.mid0.cout : 0));
+    PD_TRY(transformer(n.mid1, m0, m1, ses.kv_u[n.mid1.kv_slot]));
+    PD_TRY(resblock(n.mid2, m1, m2, emb_ptr(ses.emb_u, n.mid2, emb_row), emb_stride ? n.mid2.cout : 0));
+    h = m2;
+    const int nctl = (int)cnet.enc.size();  // index of the middle control tensor
+    for (size_t i = 0; i < n.dec.size(); ++i) {
+        DecBlock& b = n.dec[i];
+        Act skip = hs.back();
+        hs.pop_back();
+        // h = cat([h (+ mid control, :35), skip + control.pop() (:41)], dim=1)
+        Act cat = new_act(h.B, h.H, h.W, h.C + skip.C, S);
+        const Act* a_add = i == 0 ? &ses.control[nctl] : nullptr;
+        const Act* b_add = only_mid ? nullptr : &ses.control[nctl - 1 - (int)i];
+        if (!arena.dry) {
+            ++launches;
+            if (launch_concat_add(h.p, a_add ? a_add->p : nullptr, skip.p, b_add ? b_add->p : nullptr, cat.p, S, h.rows(), h.C,
+                                  skip.C, stream)) {
+                pd_set_error("concat launch failed");
+                return 1;
+            }
+        }
+        Act o;
+        PD_TRY(resblock(b.res, cat, o, emb_ptr(ses.emb_u, b.res, emb_row), emb_stride ? b.res.cout : 0));
+        if (b.attn) {
+            Act o2;
+            PD_TRY(transformer(b.st, o, o2, ses.kv_u[b.st.kv_slot]));
+            o = o2;
+        }
+        if (b.up) {
+            Act o3 = new_act(o.B, o.H * 2, o.W * 2, o.C, S);
+            PD_TRY(conv(b.upconv, o, o3, 0, 1.f, nullptr, nullptr, 0, /*ups=*/1));  // Upsample: nearest x2 then conv, :115-117
+            o = o3;
+        }
+        h = o;
+    }
+    Act a = new_act(h.B, h.H, h.W, h.C, T);
+    PD_TRY(groupnorm(h, a, n.out_g, n.out_b, 1e-5f, true));
+    eps = new_act(h.B, h.H, h.W, round_up(cfg.out_channels, 4), DT_F32);
+    PD_TRY(conv(n.outconv, a, eps));
+    return 0;
+}
+
+// ControlLDM.apply_model, cldm/cldm.py:369-382
+int pd_engine::forward_eps(int emb_row, int emb_stride, const float* scales, Act& eps) {
+    const pd_sample_args& a = ses.a;
+    const int Bf = ses.Bf;
+    Act x_in;
+    x_in.p = ses.x_in; x_in.B = Bf; x_in.H = a.h; x_in.W = a.w; x_in.C = 8; x_in.dt = DT_F32;
+    // the 13 control tensors outlive the ControlNet pass
+    int hh = a.h, ww = a.w;
+    for (size_t i = 0; i < cnet.enc.size(); ++i) {
+        if (cnet.enc[i].kind == 2) { hh /= 2; ww /= 2; }
+        ses.control[i] = new_act(Bf, hh, ww, cnet.enc[i].cout, S);
+    }
+    ses.control[cnet.enc.size()] = new_act(Bf, hh, ww, cnet.enc.back().cout, S);
+    const size_t mk = arena.mark();
+    PD_TRY(run_controlnet(x_in, emb_row, emb_stride, scales));
+    arena.release(mk);
+    if (a.guess_mode && a.use_cfg && !arena.dry) {
+        // (D) pipeline :1248-1253: the unconditional half gets zero residuals
+        for (size_t i = 0; i <= cnet.enc.size(); ++i)
+            HIP_OK(hipMemsetAsync(ses.control[i].p, 0, ses.control[i].bytes() / 2, stream));
+    }
+    PD_TRY(run_unet(x_in, emb_row, emb_stride, a.only_mid_control != 0, eps));
+    return 0;
+}

@@ -1,0 +1,230 @@
+// pdengine: engine object behind the C ABI of include/pdengine.h (host-side orchestration).
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pdengine.h"
+#include "pd_common.h"
+
+void pd_set_error(const char* fmt, ...);
+
+#define HIP_OK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            pd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+#define PD_TRY(expr)            \
+    do {                        \
+        int _r = (expr);        \
+        if (_r) return _r;      \
+    } while (0)
+
+// A GEMM weight matrix [Nalloc][Kpad] in the compute type, K-contiguous, plus its fp32 bias.
+struct WMat {
+    void* w = nullptr;
+    float* bias = nullptr;
+    int N = 0;       // weight rows the kernel sees (virtual columns; GEGLU: interleaved blocks)
+    int Nout = 0;    // logical output columns
+    int K = 0;       // logical reduction length taps*cin_pad
+    int Kpad = 0;
+    int taps = 1;
+    int cin = 0, cin_pad = 0;
+    int fan_in = 1;
+    bool geglu = false;
+};
+
+struct ConvW {
+    WMat m;
+    int cin = 0, cout = 0, k = 1, stride = 1;
+};
+
+struct ResW {
+    int cin = 0, cout = 0;
+    float *gn1_g = nullptr, *gn1_b = nullptr, *gn2_g = nullptr, *gn2_b = nullptr;
+    ConvW conv1, conv2, skip;
+    WMat emb;
+    bool has_skip = false;
+    int emb_slot = -1;  // index into the per-net table of projected time embeddings
+};
+
+struct STW {
+    int C = 0;
+    float *gn_g = nullptr, *gn_b = nullptr;
+    float* ln_g[3] = {nullptr, nullptr, nullptr};
+    float* ln_b[3] = {nullptr, nullptr, nullptr};
+    ConvW proj_in, proj_out;
+    WMat qkv, out1, q2, kv2, out2, ff1, ff2;
+    int kv_slot = -1;  // index into the per-net table of hoisted context K / V^T
+};
+
+struct EncBlock {
+    int kind = 0;  // 0 conv_in, 1 res(+attn), 2 down
+    ConvW conv;
+    ResW res;
+    bool attn = false;
+    STW st;
+    int cout = 0, ds = 1;
+};
+
+struct DecBlock {
+    ResW res;
+    bool attn = false, up = false;
+    STW st;
+    ConvW upconv;
+    int skip_c = 0, cout = 0;
+};
+
+struct NetW {
+    WMat te0, te2;
+    std::vector<EncBlock> enc;
+    ResW mid0, mid2;
+    STW mid1;
+    // UNet only
+    std::vector<DecBlock> dec;
+    float *out_g = nullptr, *out_b = nullptr;
+    ConvW outconv;
+    // ControlNet only
+    std::vector<ConvW> zero;
+    ConvW mid_out;
+    std::vector<ConvW> hint_pair, hint_query;
+    int n_emb = 0, n_kv = 0;
+    std::vector<ResW*> res_list;  // in emb_slot order
+    std::vector<STW*> st_list;    // in kv_slot order
+};
+
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape;
+    int kind = 0;  // 0 fp32 vector, 1 matrix rows (linear / conv)
+    // vector destination
+    float* vdst = nullptr;
+    bool geglu_vec = false;
+    int geglu_half = 0;  // 4C for GEGLU permutation
+    // matrix destination
+    WMat* mat = nullptr;
+    int row_off = 0;
+    bool conv = false;  // OIHW source
+    char init = 'w';    // recipe class for pd_init_random_weights: w, b, g(amma), e(beta)
+    bool loaded = false;
+};
+
+struct Act {
+    void* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    int dt = DT_F32;
+    long long rows() const { return (long long)B * H * W; }
+    size_t bytes() const { return (size_t)rows() * C * dt_size(dt); }
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, top = 0, peak = 0;
+    bool dry = false;
+    void* alloc(size_t bytes) {
+        size_t a = (top + 255) & ~(size_t)255;
+        top = a + bytes;
+        if (top > peak) peak = top;
+        if (dry) return reinterpret_cast<void*>((size_t)0x1000 + a);
+        return base + a;
+    }
+    size_t mark() const { return top; }
+    void release(size_t m) { top = m; }
+};
+
+struct KVSlot { void* K = nullptr; void* VT = nullptr; };
+
+struct Session {
+    bool active = false;
+    pd_sample_args a{};
+    int Bf = 0;
+    int S = 0;
+    std::vector<int64_t> timesteps;  // ascending (ddim_timesteps)
+    std::vector<float> alphas, alphas_prev, sigmas, sqrt_1m;
+    std::vector<float> scales_step;  // [S][13]
+    // device state
+    float* x_state = nullptr;   // [B, HW, 8] fp32
+    float* x_in = nullptr;      // [Bf, HW, 8] fp32
+    float* pred_x0 = nullptr;   // [B, HW, C]
+    float* eps_g = nullptr;     // [B, HW, C]
+    float* noise = nullptr;     // [S][B, C, HW] or null
+    void* ctx = nullptr;        // [Bf, L, Dpad] compute type
+    Act hint;                   // guided_hint [Bf, h, w, C0]
+    std::vector<KVSlot> kv_u, kv_c;
+    std::vector<float*> emb_u, emb_c;  // per ResBlock [rows, Cout]
+    int emb_rows = 0;
+    float* per_step = nullptr;  // optional [S+1][B,C,h,w]
+    Act control[PD_NUM_CONTROL];
+    size_t session_top = 0;
+};
+
+struct pd_engine {
+    pd_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool f32 = false;
+    int T = DT_BF16;  // compute (MFMA operand) type
+    int S = DT_BF16;  // residual-stream type
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> index;
+    NetW unet, cnet;
+    std::vector<void*> owned;  // device allocations (weights)
+    size_t weight_bytes = 0;
+    Arena arena;
+    Session ses;
+    int verbose = 0;
+    long long launches = 0;
+    double* gn_partial = nullptr;  // scratch for GroupNorm partial sums
+    size_t gn_partial_cap = 0;
+
+    // construction
+    int build();
+    void* dmalloc(size_t bytes);
+    void make_mat(WMat& m, int n_rows, int k_logical, int taps, int cin, bool bias, bool geglu = false);
+    void reg_mat(const std::string& name, std::vector<int64_t> shape, WMat* m, int row_off, bool conv);
+    void reg_vec(const std::string& name, int n, float** dst, char init);
+    void reg_bias(const std::string& name, WMat* m, int off, int n, bool geglu = false);
+    void build_conv(const std::string& prefix, ConvW& c, int cin, int cout, int k, int stride);
+    void build_res(const std::string& prefix, ResW& r, int cin, int cout, NetW& net);
+    void build_st(const std::string& prefix, STW& s, int ch, NetW& net);
+    void build_encoder(const std::string& prefix, NetW& net);
+    void build_middle(const std::string& prefix, NetW& net);
+
+    // weights
+    int load(const char* name, const void* data, const int64_t* shape, int ndim, int dtype);
+    int init_random(uint64_t seed);
+    int upload_vec(float* dst_dev, const float* src, int n, bool geglu, int half);
+    int upload_rows(WMat& m, int row_off, const float* src, int rows, bool conv);
+
+    // primitive ops (enqueue on stream; honour arena.dry)
+    Act new_act(int B, int H, int W, int C, int dt);
+    int gemm(const WMat& m, const Act& in, Act& out, int taps_stride, int ups, int act, float scale, const Act* R,
+             const float* rowvec, int rowvec_stride, bool a_silu, void* VT, int vt_begin, int vt_ld, int ldc_override = 0);
+    int conv(const ConvW& c, const Act& in, Act& out, int act = 0, float scale = 1.f, const Act* R = nullptr,
+             const float* rowvec = nullptr, int rowvec_stride = 0, int ups = 0);
+    int groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu);
+    int layernorm(const Act& x, Act& y, const float* g, const float* b);
+    int resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride);
+    int transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv);
+    int attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B, int Nq,
+                  int Nk, int C);
+
+    // networks
+    int run_controlnet(const Act& x_in, int emb_row, int emb_stride, const float* scales);
+    int run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_mid, Act& eps);
+    int forward_eps(int emb_row, int emb_stride, const float* scales, Act& eps);
+
+    // sessions
+    int ensure_arena(int Bf, int h, int w, int rows, bool per_step);
+    int session_setup(const pd_sample_args& a, const int64_t* t_rows, int n_rows, bool per_sample_t, bool want_per_step);
+    int compute_emb(NetW& net, std::vector<float*>& tabs, const int64_t* t, int n, int row0);
+    int begin(const pd_sample_args* a, bool want_per_step);
+    int step(int i);
+    int make_schedule(int steps, float eta, std::vector<int64_t>& ts, std::vector<float>& a, std::vector<float>& ap,
+                      std::vector<float>& sg, std::vector<float>& s1m);
+};

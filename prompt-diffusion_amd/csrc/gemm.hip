@@ -1,0 +1,314 @@
+// Implicit-GEMM convolution / linear kernel for gfx950 (MI355X, CDNA4).
+//
+// One kernel covers every contraction of the hot path: conv3x3 (stride 1/2,
+// optional fused nearest-x2 upsample gather), conv1x1, nn.Linear.  C[M,N] = A[M,K] * W[N,K]^T with
+//   M = B*Hout*Wout output pixels / tokens (NHWC rows), N = Cout, K = taps*Cin.
+// Tile: 128(M) x 160(N) x 128 bytes of K per step, 256 threads = 4 waves.  160 divides every channel
+// count of SD1.5 (320/640/960/1280/1920/2560/5120/10240), so no N padding is wasted.
+// Operands are staged global -> VGPR -> LDS (the A gather needs per-row halo masks, so no LDS-DMA),
+// double-buffered, one barrier per K step; LDS rows are 128 B with a 16-B-chunk XOR swizzle
+// (chunk ^= (row>>1)&7) that makes the ds_read_b128 fragment reads conflict-free.
+// The MFMA is issued "swapped" (weights as the A operand, activations as B) so every lane ends up with
+// 4 consecutive output channels of one pixel: bias/residual/time-embedding reads and the store are
+// 8-16 B vectors along the NHWC channel axis.
+// Precision modes share the byte-level data path: bf16 -> v_mfma_f32_16x16x32_bf16 (8 k per lane),
+// fp32 -> 4 x v_mfma_f32_16x16x4_f32 on the same 16-byte fragment (k order permuted identically on
+// both operands, which leaves the dot product unchanged).
+#include "pd_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 160, BKB = 128;  // tile; BKB = bytes of K per LDS row
+constexpr int NTHREADS = 256;
+constexpr int A_ITERS = BM * 8 / NTHREADS;  // 16-byte chunks per thread per K step (4)
+constexpr int B_ITERS = BN * 8 / NTHREADS;  // (5)
+constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row * BKB) + (((chunk ^ (row >> 1)) & 7) << 4); }
+
+template <bool F32>
+__device__ __forceinline__ void mma(const uint4& w, const uint4& a, f32x4& acc) {
+    if constexpr (F32) {
+        const float* wf = reinterpret_cast<const float*>(&w);
+        const float* af = reinterpret_cast<const float*>(&a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[j], acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a),
+                                                      acc, 0, 0, 0);
+    }
+}
+
+// convert 8 fp32 (two uint4) to 8 bf16 (one uint4)
+__device__ __forceinline__ uint4 cvt8(const uint4& lo, const uint4& hi, bool do_silu) {
+    float f[8];
+    const float* a = reinterpret_cast<const float*>(&lo);
+    const float* b = reinterpret_cast<const float*>(&hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+    if (do_silu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+    }
+    uint4 r;
+    r.x = pack2bf(f[0], f[1]); r.y = pack2bf(f[2], f[3]); r.z = pack2bf(f[4], f[5]); r.w = pack2bf(f[6], f[7]);
+    return r;
+}
+
+template <bool F32, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
+    constexpr int EB = F32 ? 4 : 2;
+    constexpr int VEC = 16 / EB;    // elements per 16-byte chunk
+    constexpr int BKE = BKB / EB;   // elements of K per step
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD/L2; give each XCD a contiguous run of
+    // tiles (n fastest) so neighbouring tiles that share the A rows hit the same L2.
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+    const int nblk = mtiles * ntiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int bm = bid / ntiles, bn = bid % ntiles;
+    const int kslice = blockIdx.y;
+
+    // ---- per-thread staging assignment
+    const int chunk = tid & 7;
+    const int row0 = tid >> 3;  // + 32*i
+    int a_b[A_ITERS], a_y[A_ITERS], a_x[A_ITERS];
+    bool a_ok[A_ITERS];
+    size_t a_base[A_ITERS];
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int m = bm * BM + row0 + 32 * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        if (p.taps == 1) {
+            a_base[i] = (size_t)mm * p.lda;
+            a_b[i] = a_y[i] = a_x[i] = 0;
+        } else {
+            const int b = mm / p.rows_per_sample;
+            const int rem = mm - b * p.rows_per_sample;
+            const int oy = rem / p.Wout;
+            a_b[i] = b;
+            a_y[i] = oy * p.stride - 1;
+            a_x[i] = (rem - oy * p.Wout) * p.stride - 1;
+            a_base[i] = 0;
+        }
+    }
+    size_t w_base[B_ITERS];
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+        int n = bn * BN + row0 + 32 * i;
+        n = n < p.N ? n : p.N - 1;  // clamp: columns >= N are never stored
+        w_base[i] = (size_t)n * p.Kpad;
+    }
+
+    const int ktiles_all = p.Kpad / BKE;
+    int kt0 = 0, kt1 = ktiles_all;
+    if (p.splitk > 1) {
+        const int per = (ktiles_all + p.splitk - 1) / p.splitk;
+        kt0 = kslice * per;
+        kt1 = min(ktiles_all, kt0 + per);
+    }
+
+    uint4 ra[A_ITERS], rb[B_ITERS];
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+    const bool a_f32 = p.a_dt == DT_F32;
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BKE + chunk * VEC;
+        const bool kok = k0 < p.K;
+        int ky = 0, kx = 0, cof = k0;
+        if (p.taps != 1) {
+            const int tap = k0 / p.Cin;
+            cof = k0 - tap * p.Cin;
+            ky = tap / 3;
+            kx = tap - ky * 3;
+        }
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            bool ok = a_ok[i] && kok;
+            size_t idx;
+            if (p.taps == 1) {
+                idx = a_base[i] + cof;
+            } else {
+                const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                ok = ok && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+                idx = ((size_t)(a_b[i] * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) * p.lda + cof;
+            }
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                if constexpr (F32) {
+                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p.A) + idx);
+                    if (p.a_silu) {
+                        float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
+                    }
+                } else if (a_f32) {
+                    const uint4* s = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p.A) + idx);
+                    v = cvt8(s[0], s[1], p.a_silu != 0);
+                } else {
+                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.A) + idx);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            rb[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.W) +
+                                                    (w_base[i] + (size_t)kt * BKE + chunk * VEC) * EB);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sa = smem + buf * (BM + BN) * BKB;
+        char* sb = sa + BM * BKB;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<uint4*>(sa + swz(row0 + 32 * i, chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<uint4*>(sb + swz(row0 + 32 * i, chunk)) = rb[i];
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt0 < kt1) {
+        gload(kt0);
+        lstore(0);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) gload(kt + 1);
+        const char* sa = smem + buf * (BM + BN) * BKB;
+        const char* sb = sa + BM * BKB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[MT], wf[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mma<F32>(wf[n], af[m], acc[n][m]);
+        }
+        if (kt + 1 < kt1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels n..n+3 (rows of the swapped MFMA) of pixel m
+    if (p.splitk > 1) {
+        float* Cf = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int gm = bm * BM + wm * WTM + m * 16 + fr;
+            if (gm >= p.M) continue;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
+                if (gn >= p.N) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(Cf + (size_t)gm * p.ldc + gn + j, acc[n][m][j]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int gm = bm * BM + wm * WTM + m * 16 + fr;
+        if (gm >= p.M) continue;
+        const int sample = gm / p.rows_per_sample;
+        const int tok = gm - sample * p.rows_per_sample;
+        if (p.act == 2) {
+            // GEGLU: virtual columns [0,80) of this tile are x, [80,160) the gate (weights interleaved at load)
+            if constexpr (NT == 10) {
+#pragma unroll
+                for (int n = 0; n < 5; ++n) {
+                    const int vn = bn * BN + n * 16 + fq * 4;
+                    const int on = bn * (BN / 2) + n * 16 + fq * 4;
+                    if (on >= p.Nout) continue;
+                    f32x4 x = acc[n][m], g = acc[n + 5][m];
+                    if (p.bias) {
+                        x += *reinterpret_cast<const f32x4*>(p.bias + vn);
+                        g += *reinterpret_cast<const f32x4*>(p.bias + vn + BN / 2);
+                    }
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = x[j] * gelu_f(g[j]);
+                    store4(p.C, (size_t)gm * p.ldc + on, p.c_dt, o);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
+            if (gn >= p.N) continue;
+            f32x4 v = acc[n][m];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + gn);
+            if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (size_t)sample * p.rowvec_stride + gn);
+            if (p.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+            }
+            v *= p.out_scale;
+            if (p.R) v += load4(p.R, (size_t)gm * p.ldr + gn, p.r_dt);
+            if (gn >= p.vt_begin) {
+                // transposed store (attention V^T): [sample][channel][token]
+                const size_t base = ((size_t)sample * (p.N - p.vt_begin) + (gn - p.vt_begin)) * p.vt_ld + tok;
+                if (p.c_dt == DT_F32) {
+                    float* o = reinterpret_cast<float*>(p.VT);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[base + (size_t)j * p.vt_ld] = v[j];
+                } else {
+                    uint16_t* o = reinterpret_cast<uint16_t*>(p.VT);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[base + (size_t)j * p.vt_ld] = f2bf(v[j]);
+                }
+            } else {
+                store4(p.C, (size_t)gm * p.ldc + gn, p.c_dt, v);
+            }
+        }
+    }
+}
+
+template <bool F32, int WM, int WN>
+int launch_one(const GemmParams& p, hipStream_t s) {
+    static bool attr_done = false;
+    auto kfn = igemm_kernel<F32, WM, WN>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SMEM_BYTES) != hipSuccess)
+            return 1;
+        attr_done = true;
+    }
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+    dim3 grid(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1);
+    hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+}  // namespace
+
+int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return 0;
+    if (p.act == 2) return f32mode ? launch_one<true, 4, 1>(p, s) : launch_one<false, 4, 1>(p, s);
+    return f32mode ? launch_one<true, 2, 2>(p, s) : launch_one<false, 2, 2>(p, s);
+}

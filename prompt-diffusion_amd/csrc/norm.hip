@@ -1,0 +1,230 @@
+// GroupNorm (+SiLU) and LayerNorm for NHWC activations on gfx950.  HBM-bound passes.
+//
+// GroupNorm32 (reference util.py:217-219: 32 groups, fp32 statistics) runs as two coalesced sweeps:
+//   gn_stats : grid (nchunk, B); each block reads a contiguous slab of pixels x all channels with
+//              16-byte loads and reduces per-group {sum, sum of squares} in fp64 -> partial[B][nchunk][G][2]
+//   gn_apply : folds the partials (fp64 mean / biased variance, rstd = 1/sqrt(var+eps)), then one more
+//              coalesced sweep writes (x-mean)*rstd*gamma+beta (optionally SiLU'd) in the compute type.
+// LayerNorm (nn.LayerNorm, eps 1e-5, attention.py:263-265): one wave per token row, row held in
+// registers, two-pass variance in fp32.
+#include "pd_common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+
+template <bool XF32>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const void* __restrict__ x, double* __restrict__ partial,
+                                                               int HW, int C, int groups, int nchunk) {
+    constexpr int VEC = XF32 ? 4 : 8;
+    __shared__ double s_sum[64], s_sq[64];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < 64) { s_sum[tid] = 0.0; s_sq[tid] = 0.0; }
+    __syncthreads();
+    const int ppc = (HW + nchunk - 1) / nchunk;
+    const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+    const int nvec = C / VEC;
+    const int lanes = min(nvec, GN_THREADS);
+    const int rows_par = GN_THREADS / lanes;
+    const int pr = tid / lanes, vc = tid - pr * lanes;
+    const int cpg = C / groups;
+    if (pr < rows_par) {
+        for (int v = vc; v < nvec; v += lanes) {
+            float s[VEC], q[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
+            double ds[VEC], dq[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { ds[j] = 0.0; dq[j] = 0.0; }
+            int cnt = 0;
+            for (int p = p0 + pr; p < p1; p += rows_par) {
+                const size_t idx = ((size_t)b * HW + p) * C + (size_t)v * VEC;
+                float f[VEC];
+                if constexpr (XF32) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + idx);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = t[j];
+                } else {
+                    const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + idx);
+                    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f[2 * j] = __uint_as_float(w[j] << 16);
+                        f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+                if (++cnt == 16) {  // flush short fp32 runs into fp64
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) { ds[j] += s[j]; dq[j] += q[j]; s[j] = 0.f; q[j] = 0.f; }
+                    cnt = 0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                ds[j] += s[j];
+                dq[j] += q[j];
+                const int g = (v * VEC + j) / cpg;
+                atomicAdd(&s_sum[g], ds[j]);
+                atomicAdd(&s_sq[g], dq[j]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        double* o = partial + (((size_t)b * nchunk + chunk) * groups + tid) * 2;
+        o[0] = s_sum[tid];
+        o[1] = s_sq[tid];
+    }
+}
+
+template <bool XF32, bool YF32>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                               const double* __restrict__ partial,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int HW, int C, int groups, int nchunk, int nblk_per_sample,
+                                                               float eps, int do_silu) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < groups) {
+        double s = 0.0, q = 0.0;
+        for (int c = 0; c < nchunk; ++c) {
+            const double* o = partial + (((size_t)b * nchunk + c) * groups + tid) * 2;
+            s += o[0];
+            q += o[1];
+        }
+        const double n = (double)HW * (double)(C / groups);
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    const int nvec4 = C / 4;
+    const long long total = (long long)HW * nvec4;
+    const long long per = (total + nblk_per_sample - 1) / nblk_per_sample;
+    const long long i0 = blockIdx.x * per, i1 = min(total, i0 + per);
+    for (long long i = i0 + tid; i < i1; i += GN_THREADS) {
+        const int v = (int)(i % nvec4);
+        const size_t idx = (size_t)b * HW * C + (size_t)i * 4;
+        f32x4 t = load4(x, idx, XF32 ? DT_F32 : DT_BF16);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + v * 4);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(beta + v * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int grp = (v * 4 + j) / cpg;
+            float r = (t[j] - s_mean[grp]) * s_rstd[grp] * g[j] + be[j];
+            if (do_silu) r = silu_f(r);
+            o[j] = r;
+        }
+        store4(y, idx, YF32 ? DT_F32 : DT_BF16, o);
+    }
+}
+
+// one wave per row; C <= 64*MAXV*4
+template <bool XF32, bool YF32, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec4 = C / 4;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nvec4) {
+            v[k] = load4(x, (size_t)row * C + (size_t)vi * 4, XF32 ? DT_F32 : DT_BF16);
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        } else {
+            v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nvec4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[k][j] - mean; q = fmaf(d, d, q); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nvec4) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + vi * 4);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + vi * 4);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[k][j] - mean) * rstd * g[j] + be[j];
+            store4(y, (size_t)row * C + (size_t)vi * 4, YF32 ? DT_F32 : DT_BF16, o);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s) {
+    if (groups > 64 || C % groups || C % 8) return 1;
+    dim3 grid(nchunk, B);
+    if (x_dt == DT_F32)
+        hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_THREADS), 0, s, x, partial, HW, C, groups, nchunk);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_THREADS), 0, s, x, partial, HW, C, groups, nchunk);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
+                    const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s) {
+    long long total = (long long)HW * (C / 4);
+    int nblk = (int)((total + GN_THREADS * 8 - 1) / (GN_THREADS * 8));
+    if (nblk < 1) nblk = 1;
+    if (nblk > 512) nblk = 512;
+    dim3 grid(nblk, B);
+#define GN_AP(XF, YF)                                                                                                 \
+    hipLaunchKernelGGL((gn_apply_kernel<XF, YF>), grid, dim3(GN_THREADS), 0, s, x, y, partial, gamma, beta, HW, C, \
+                       groups, nchunk, nblk, eps, silu)
+    if (x_dt == DT_F32 && y_dt == DT_F32) GN_AP(true, true);
+    else if (x_dt == DT_F32) GN_AP(true, false);
+    else if (y_dt == DT_F32) GN_AP(false, true);
+    else GN_AP(false, false);
+#undef GN_AP
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_layernorm(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta, int rows,
+                     int C, float eps, hipStream_t s) {
+    if (C % 4 || C > 64 * 4 * 8) return 1;
+    dim3 grid((rows + 3) / 4);
+#define LN_L(XF, YF, MV)                                                                                       \
+    hipLaunchKernelGGL((layernorm_kernel<XF, YF, MV>), grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps)
+#define LN_D(MV)                                                  \
+    do {                                                          \
+        if (x_dt == DT_F32 && y_dt == DT_F32) LN_L(true, true, MV);   \
+        else if (x_dt == DT_F32) LN_L(true, false, MV);           \
+        else if (y_dt == DT_F32) LN_L(false, true, MV);           \
+        else LN_L(false, false, MV);                              \
+    } while (0)
+    const int nv = (C / 4 + 63) / 64;
+    if (nv <= 2) LN_D(2);
+    else if (nv <= 5) LN_D(5);
+    else LN_D(8);
+#undef LN_D
+#undef LN_L
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}

@@ -1,0 +1,167 @@
+// Per-operator parity hooks (declared in include/pdengine_ops.h): run ONE kernel of the hot path on
+// host arrays in the reference's own layouts, so tests/ can compare each HIP kernel with the oracle.
+// Not used by the sampling path.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pdengine_ops.h"
+#include "engine.h"
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) p = nullptr; else { hipMemset(p, 0, bytes ? bytes : 16); hipDeviceSynchronize(); } }
+    ~DevBuf() { if (p) hipFree(p); }
+};
+struct TempMat {
+    pd_engine* e;
+    size_t owned0;
+    explicit TempMat(pd_engine* e_) : e(e_), owned0(e_->owned.size()) {}
+    ~TempMat() {
+        while (e->owned.size() > owned0) { hipFree(e->owned.back()); e->owned.pop_back(); }
+    }
+};
+int to_dev_nhwc(pd_engine* e, const float* host, void* dst, int dt, int B, int C, int H, int W, int Cpad) {
+    DevBuf tmp((size_t)B * C * H * W * 4);
+    if (!tmp.p) return 1;
+    HIP_OK(hipMemcpy(tmp.p, host, (size_t)B * C * H * W * 4, hipMemcpyHostToDevice));
+    if (launch_nchw_to_nhwc(reinterpret_cast<const float*>(tmp.p), dst, dt, B, C, H, W, Cpad, e->stream)) return 1;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+int from_dev_nhwc(pd_engine* e, const void* src, int dt, float* host, int B, int C, int H, int W, int Cpad) {
+    DevBuf tmp((size_t)B * C * H * W * 4);
+    if (!tmp.p) return 1;
+    if (launch_nhwc_to_nchw(src, dt, reinterpret_cast<float*>(tmp.p), B, C, H, W, Cpad, 1.f, e->stream)) return 1;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipMemcpy(host, tmp.p, (size_t)B * C * H * W * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+}  // namespace
+
+extern "C" {
+
+// y = conv2d(x, w, b, stride, padding = k/2) [+ SiLU] [* scale] [+ residual]; x NCHW fp32, w OIHW.
+int pd_op_conv2d(pd_engine* e, const float* x, const float* w, const float* bias, const float* residual, int B, int Cin, int H,
+                 int W, int Cout, int k, int stride, int upsample, int act_silu, float scale, int stream_out, float* y) {
+    if (!e || !x || !w || !y) { pd_set_error("null argument"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    TempMat guard(e);
+    ConvW c;
+    c.cin = Cin; c.cout = Cout; c.k = k; c.stride = stride;
+    e->make_mat(c.m, Cout, Cin * k * k, k * k, Cin, true);
+    if (!c.m.w) { pd_set_error("allocation failed"); return 1; }
+    PD_TRY(e->upload_rows(c.m, 0, w, Cout, true));
+    if (bias) PD_TRY(e->upload_vec(c.m.bias, bias, Cout, false, 0));
+    const int Hv = H << upsample, Wv = W << upsample;
+    const int Ho = stride == 2 ? (Hv + 1) / 2 : Hv, Wo = stride == 2 ? (Wv + 1) / 2 : Wv;
+    const int cpad = c.m.cin_pad, odt = stream_out ? e->S : e->T, copad = round_up(Cout, 4);
+    DevBuf in((size_t)B * H * W * cpad * dt_size(e->T)), out((size_t)B * Ho * Wo * copad * dt_size(odt)),
+        res((size_t)B * Ho * Wo * copad * dt_size(e->S));
+    if (!in.p || !out.p || !res.p) { pd_set_error("allocation failed"); return 1; }
+    PD_TRY(to_dev_nhwc(e, x, in.p, e->T, B, Cin, H, W, cpad));
+    Act a, o, r;
+    a.p = in.p; a.B = B; a.H = H; a.W = W; a.C = cpad; a.dt = e->T;
+    o.p = out.p; o.B = B; o.H = Ho; o.W = Wo; o.C = copad; o.dt = odt;
+    r = o; r.p = res.p; r.dt = e->S;
+    if (residual) PD_TRY(to_dev_nhwc(e, residual, res.p, e->S, B, Cout, Ho, Wo, copad));
+    PD_TRY(e->conv(c, a, o, act_silu, scale, residual ? &r : nullptr, nullptr, 0, upsample));
+    return from_dev_nhwc(e, out.p, odt, y, B, Cout, Ho, Wo, copad);
+}
+
+// y[M,N] = act(x[M,K] @ w[N,K]^T + b) ; geglu: w [2*N, K] -> y[M,N] = (x w_a + b_a) * gelu(x w_g + b_g)
+int pd_op_linear(pd_engine* e, const float* x, const float* w, const float* bias, int M, int K, int N, int geglu, int a_silu,
+                 float* y) {
+    if (!e || !x || !w || !y) { pd_set_error("null argument"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    TempMat guard(e);
+    WMat m;
+    const int rows = geglu ? 2 * N : N;
+    e->make_mat(m, rows, K, 1, K, true, geglu != 0);
+    if (!m.w) { pd_set_error("allocation failed"); return 1; }
+    if (K % 8) { pd_set_error("K must be a multiple of 8"); return 1; }
+    PD_TRY(e->upload_rows(m, 0, w, rows, false));
+    if (bias) PD_TRY(e->upload_vec(m.bias, bias, rows, geglu != 0, N));
+    const int adt = a_silu ? DT_F32 : e->T;
+    DevBuf in((size_t)M * K * 4), out((size_t)M * round_up(N, 4) * 4);
+    if (!in.p || !out.p) { pd_set_error("allocation failed"); return 1; }
+    {
+        DevBuf tmp((size_t)M * K * 4);
+        HIP_OK(hipMemcpy(tmp.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
+        if (launch_cast_rows(reinterpret_cast<const float*>(tmp.p), in.p, adt, M, K, K, e->stream)) return 1;
+        HIP_OK(hipStreamSynchronize(e->stream));
+    }
+    Act a, o;
+    a.p = in.p; a.B = M; a.H = 1; a.W = 1; a.C = K; a.dt = adt;
+    o.p = out.p; o.B = M; o.H = 1; o.W = 1; o.C = round_up(N, 4); o.dt = DT_F32;
+    PD_TRY(e->gemm(m, a, o, 1, 0, 0, 1.f, nullptr, nullptr, 0, a_silu != 0, nullptr, 0, 0));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    std::vector<float> host((size_t)M * o.C);
+    HIP_OK(hipMemcpy(host.data(), out.p, host.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < M; ++i) memcpy(y + (size_t)i * N, host.data() + (size_t)i * o.C, (size_t)N * 4);
+    return 0;
+}
+
+int pd_op_groupnorm(pd_engine* e, const float* x, const float* gamma, const float* beta, int B, int C, int H, int W, float eps,
+                    int silu, float* y) {
+    if (!e || !x || !gamma || !beta || !y) { pd_set_error("null argument"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    DevBuf in((size_t)B * H * W * C * dt_size(e->S)), out((size_t)B * H * W * C * dt_size(e->T)), g((size_t)C * 4 + 16), b((size_t)C * 4 + 16);
+    if (!in.p || !out.p || !g.p || !b.p) { pd_set_error("allocation failed"); return 1; }
+    HIP_OK(hipMemcpy(g.p, gamma, (size_t)C * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(b.p, beta, (size_t)C * 4, hipMemcpyHostToDevice));
+    PD_TRY(to_dev_nhwc(e, x, in.p, e->S, B, C, H, W, C));
+    Act a, o;
+    a.p = in.p; a.B = B; a.H = H; a.W = W; a.C = C; a.dt = e->S;
+    o = a; o.p = out.p; o.dt = e->T;
+    PD_TRY(e->groupnorm(a, o, reinterpret_cast<float*>(g.p), reinterpret_cast<float*>(b.p), eps, silu != 0));
+    return from_dev_nhwc(e, out.p, e->T, y, B, C, H, W, C);
+}
+
+int pd_op_layernorm(pd_engine* e, const float* x, const float* gamma, const float* beta, int rows, int C, float* y) {
+    if (!e || !x || !gamma || !beta || !y) { pd_set_error("null argument"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    DevBuf tmp((size_t)rows * C * 4), in((size_t)rows * C * dt_size(e->S)), out((size_t)rows * C * 4), g((size_t)C * 4 + 16), b((size_t)C * 4 + 16);
+    if (!tmp.p || !in.p || !out.p || !g.p || !b.p) { pd_set_error("allocation failed"); return 1; }
+    HIP_OK(hipMemcpy(g.p, gamma, (size_t)C * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(b.p, beta, (size_t)C * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(tmp.p, x, (size_t)rows * C * 4, hipMemcpyHostToDevice));
+    if (launch_cast_rows(reinterpret_cast<const float*>(tmp.p), in.p, e->S, rows, C, C, e->stream)) return 1;
+    Act a, o;
+    a.p = in.p; a.B = rows; a.H = 1; a.W = 1; a.C = C; a.dt = e->S;
+    o = a; o.p = out.p; o.dt = DT_F32;
+    PD_TRY(e->layernorm(a, o, reinterpret_cast<float*>(g.p), reinterpret_cast<float*>(b.p)));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipMemcpy(y, out.p, (size_t)rows * C * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// softmax(q k^T dh^-0.5) v per head; q [B,Nq,C], k/v [B,Nk,C] fp32, C = heads*dh (heads from the engine config)
+int pd_op_attention(pd_engine* e, const float* q, const float* k, const float* v, int B, int Nq, int Nk, int C, float* o) {
+    if (!e || !q || !k || !v || !o) { pd_set_error("null argument"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    const int lpad = round_up(Nk, 8);
+    const size_t eb = dt_size(e->T);
+    std::vector<float> vt((size_t)B * C * lpad, 0.f);
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < Nk; ++n)
+            for (int c = 0; c < C; ++c) vt[((size_t)b * C + c) * lpad + n] = v[((size_t)b * Nk + n) * C + c];
+    DevBuf tq((size_t)B * Nq * C * 4), tk((size_t)B * Nk * C * 4), tv(vt.size() * 4);
+    DevBuf dq((size_t)B * Nq * C * eb), dk((size_t)B * Nk * C * eb), dv(vt.size() * eb), dout((size_t)B * Nq * C * eb), fo((size_t)B * Nq * C * 4);
+    if (!tq.p || !tk.p || !tv.p || !dq.p || !dk.p || !dv.p || !dout.p || !fo.p) { pd_set_error("allocation failed"); return 1; }
+    HIP_OK(hipMemcpy(tq.p, q, (size_t)B * Nq * C * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(tk.p, k, (size_t)B * Nk * C * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(tv.p, vt.data(), vt.size() * 4, hipMemcpyHostToDevice));
+    if (launch_cast_rows(reinterpret_cast<const float*>(tq.p), dq.p, e->T, (long long)B * Nq, C, C, e->stream)) return 1;
+    if (launch_cast_rows(reinterpret_cast<const float*>(tk.p), dk.p, e->T, (long long)B * Nk, C, C, e->stream)) return 1;
+    if (launch_cast_rows(reinterpret_cast<const float*>(tv.p), dv.p, e->T, (long long)B * C, lpad, lpad, e->stream)) return 1;
+    PD_TRY(e->attention(dq.p, C, dk.p, C, dv.p, lpad, dout.p, C, B, Nq, Nk, C));
+    if (launch_nhwc_to_nchw(dout.p, e->T, reinterpret_cast<float*>(fo.p), 1, 1, 1, B * Nq * C, 1, 1.f, e->stream)) return 1;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipMemcpy(o, fo.p, (size_t)B * Nq * C * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+"""Per-kernel parity on the GPU: each HIP kernel family (through the C ABI's pd_op_* hooks) against
+the NumPy oracle on the same seeded inputs.  Tolerances: fp32 mode 2e-5 of the tensor's max
+(different summation order only); bf16 mode 2e-2 (8-bit mantissa operands, fp32 accumulate)."""
+import numpy as np
+import pytest
+
+from oracle import pd_oracle as O
+from prompt_diffusion_amd import engine as E
+from prompt_diffusion_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 2e-5, "bf16": 2e-2}
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module", params=["f32", "bf16"])
+def eng(request):
+    e = E.Engine(W.TINY, precision=request.param)
+    e.prec = request.param
+    yield e
+    e.close()
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,ups", [
+    (2, 64, 8, 8, 128, 3, 1, False),     # plain 3x3
+    (1, 4, 16, 16, 64, 3, 1, False),     # conv_in: Cin padded 4 -> 8
+    (2, 6, 32, 32, 16, 3, 1, False),     # hint conv: tiny channels, K = 72
+    (2, 32, 10, 10, 32, 3, 2, False),    # Downsample (stride 2, even)
+    (1, 32, 9, 7, 48, 3, 2, False),      # stride 2, odd sizes
+    (2, 32, 6, 6, 32, 3, 1, True),       # Upsample: nearest x2 fused in the gather
+    (2, 96, 12, 12, 96, 1, 1, False),    # 1x1
+    (3, 320, 16, 16, 320, 3, 1, False),  # SD1.5 shape, N = 2 x 160 tiles, M = 768
+    (1, 320, 8, 8, 4, 3, 1, False),      # out conv: N = 4
+    (1, 200, 5, 5, 168, 3, 1, False),    # ragged M and N tiles, Cin not a multiple of the K tile
+])
+def test_conv2d(eng, B, Cin, H, W, Cout, k, stride, ups):
+    g = rng(1)
+    x = g.standard_normal((B, Cin, H, W), dtype=np.float32)
+    w = (g.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = g.standard_normal(Cout, dtype=np.float32) * 0.1
+    xin = np.repeat(np.repeat(x, 2, axis=2), 2, axis=3) if ups else x
+    ref = O.conv2d(xin, w, b, stride=stride, padding=k // 2)
+    got = eng.op_conv2d(x, w, b, stride=stride, upsample=ups)
+    assert got.shape == ref.shape
+    assert relerr(got, ref) < TOL[eng.prec]
+
+
+def test_conv2d_epilogues(eng):
+    g = rng(2)
+    x = g.standard_normal((2, 64, 8, 8), dtype=np.float32)
+    w = (g.standard_normal((64, 64, 3, 3), dtype=np.float32) / 24).astype(np.float32)
+    b = g.standard_normal(64, dtype=np.float32) * 0.1
+    r = g.standard_normal((2, 64, 8, 8), dtype=np.float32)
+    ref = O.conv2d(x, w, b)
+    assert relerr(eng.op_conv2d(x, w, b, silu=True), O.silu(ref)) < TOL[eng.prec]
+    assert relerr(eng.op_conv2d(x, w, b, scale=0.825, residual=r, stream_out=True), ref * 0.825 + r) < TOL[eng.prec]
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 64, 256), (7, 1280, 320), (128, 320, 960), (77, 96, 512), (1, 320, 1280)])
+def test_linear(eng, M, K, N):
+    g = rng(3)
+    x = g.standard_normal((M, K), dtype=np.float32)
+    w = (g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = g.standard_normal(N, dtype=np.float32) * 0.1
+    assert relerr(eng.op_linear(x, w, b), O.linear(x, w, b)) < TOL[eng.prec]
+    assert relerr(eng.op_linear(x, w, None), O.linear(x, w)) < TOL[eng.prec]
+    # emb_layers: Linear(SiLU(emb)), openaimodel.py:217-223
+    assert relerr(eng.op_linear(x, w, b, a_silu=True), O.linear(O.silu(x), w, b)) < TOL[eng.prec]
+
+
+@pytest.mark.parametrize("M,C", [(200, 64), (64, 320), (33, 40)])
+def test_geglu(eng, M, C):
+    g = rng(4)
+    x = g.standard_normal((M, C), dtype=np.float32)
+    w = (g.standard_normal((8 * C, C), dtype=np.float32) / np.sqrt(C)).astype(np.float32)
+    b = g.standard_normal(8 * C, dtype=np.float32) * 0.1
+    h = O.linear(x, w, b)
+    a, gate = np.split(h, 2, axis=-1)
+    assert relerr(eng.op_linear(x, w, b, geglu=True), a * O.gelu(gate)) < TOL[eng.prec]
+
+
+@pytest.mark.parametrize("B,C,H,W,eps,silu", [(2, 64, 8, 8, 1e-5, True), (3, 320, 16, 16, 1e-6, False),
+                                               (1, 960, 4, 4, 1e-5, True), (2, 128, 5, 3, 1e-5, True),
+                                               (1, 2560, 8, 8, 1e-5, True)])
+def test_groupnorm(eng, B, C, H, W, eps, silu):
+    g = rng(5)
+    x = (g.standard_normal((B, C, H, W), dtype=np.float32) * 2 + 0.5).astype(np.float32)
+    ga = 1 + 0.1 * g.standard_normal(C, dtype=np.float32)
+    be = 0.1 * g.standard_normal(C, dtype=np.float32)
+    if eng.prec == "bf16":  # the kernel sees the bf16-rounded stream; give the oracle the same input
+        import torch
+        x = torch.from_numpy(x).bfloat16().float().numpy()
+    ref = O.group_norm(x, ga, be, eps=eps)
+    ref = O.silu(ref) if silu else ref
+    assert relerr(eng.op_groupnorm(x, ga, be, eps, silu), ref) < (1e-5 if eng.prec == "f32" else 1e-2)
+
+
+@pytest.mark.parametrize("rows,C", [(100, 64), (9, 320), (5, 1280), (257, 640)])
+def test_layernorm(eng, rows, C):
+    g = rng(6)
+    x = (g.standard_normal((rows, C), dtype=np.float32) * 3 - 1).astype(np.float32)
+    ga = 1 + 0.1 * g.standard_normal(C, dtype=np.float32)
+    be = 0.1 * g.standard_normal(C, dtype=np.float32)
+    if eng.prec == "bf16":
+        import torch
+        x = torch.from_numpy(x).bfloat16().float().numpy()
+    assert relerr(eng.op_layernorm(x, ga, be), O.layer_norm(x, ga, be)) < 1e-5
+
+
+def _attn_ref(q, k, v, heads):
+    B, Nq, C = q.shape
+    dh = C // heads
+    sp = lambda t: t.reshape(t.shape[0], t.shape[1], heads, dh).transpose(0, 2, 1, 3).astype(np.float64)
+    qh, kh, vh = sp(q), sp(k), sp(v)
+    s = qh @ kh.transpose(0, 1, 3, 2) * dh ** -0.5
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    return (p @ vh).transpose(0, 2, 1, 3).reshape(B, Nq, C).astype(np.float32)
+
+
+@pytest.mark.parametrize("B,Nq,Nk,C", [
+    (2, 256, 256, 64),    # dh 8, self
+    (1, 64, 64, 256),     # dh 32
+    (2, 100, 77, 320),    # dh 40, cross (ragged key tile, ragged query block)
+    (1, 1024, 1024, 320), # dh 40, self, many key tiles
+    (1, 192, 192, 640),   # dh 80
+    (2, 48, 77, 1280),    # dh 160, cross
+    (1, 12, 12, 128),     # dh 16, tiny ragged
+])
+def test_attention(eng, B, Nq, Nk, C):
+    g = rng(7)
+    q = g.standard_normal((B, Nq, C), dtype=np.float32)
+    k = g.standard_normal((B, Nk, C), dtype=np.float32)
+    v = g.standard_normal((B, Nk, C), dtype=np.float32)
+    ref = _attn_ref(q, k, v, eng.cfg.num_heads)
+    got = eng.op_attention(q, k, v)
+    assert relerr(got, ref) < (3e-5 if eng.prec == "f32" else 2e-2)
+
+
+def test_attention_peaked_softmax(eng):
+    """One key dominates each row at a chosen tile: exercises the online-softmax rescale branch."""
+    g = rng(8)
+    B, N, C = 1, 320, 64
+    q = g.standard_normal((B, N, C), dtype=np.float32)
+    k = g.standard_normal((B, N, C), dtype=np.float32)
+    v = g.standard_normal((B, N, C), dtype=np.float32)
+    k[0, 200] = q[0, 5] * 6.0   # spike for query 5 in the 4th key tile
+    k[0, 70] = q[0, 300] * 6.0  # spike in the 2nd key tile
+    ref = _attn_ref(q, k, v, eng.cfg.num_heads)
+    assert relerr(eng.op_attention(q, k, v), ref) < (3e-5 if eng.prec == "f32" else 3e-2)
