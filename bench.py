@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Prompt-Diffusion DDIM hot path on MI355X.
+
+Metric (BASELINE.json): images/sec @ 512x512, 50-step DDIM, bs=8 (per GPU; weak scaling:
+N GPUs sample 8*N images, batch-sharded, one RCCL all-gather of the final latents per pass).
+A "step" (--steps K) is one full pass of the hot path over one batch: pd_ddim_sample of 8 images =
+50 denoising steps x (ControlNet + UNet on the CFG-doubled batch 16) + CFG + DDIM update, with every
+input already resident in HBM (torch CUDA tensors handed over as device pointers).  Weights are
+random-initialised on the device (no checkpoint exists offline), inputs synthetic.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+# algorithmic FLOPs per forward-sample at latent 64x64 with loop invariants hoisted
+GF_PER_FWD_SAMPLE_64 = 1067.5
+
+
+def cpu_baseline(ddim_steps: int):
+    """The oracle (NumPy restatement, kind 'port') timed on the host cores on a bounded sample of the same
+    workload: ONE denoising step of ONE 512x512 image (CFG pair, latent 64x64); images/sec is
+    extrapolated as 1 / (ddim_steps * t_step)."""
+    import numpy as np
+    from oracle import pd_oracle as O
+    from prompt_diffusion_amd import weights as W
+    cfg = W.SD15
+    sd = W.synth_state_dict(cfg)
+    lay = O.make_layouts(cfg, W)
+    inp = W.synth_inputs(cfg, 1, 64, 64)
+    cond = dict(c_crossattn=inp["ctx_cond"], example_pair=inp["pair"], query=inp["query"])
+    unc = dict(c_crossattn=inp["ctx_uncond"], example_pair=inp["pair"], query=inp["query"])
+    sched = O.make_schedule(ddim_steps)
+    t0 = time.time()
+    O.p_sample_ddim(sd, cfg, lay, sched, inp["x_T"], cond, unc, ddim_steps - 1, int(sched["ddim_timesteps"][-1]), 7.5)
+    dt = time.time() - t0
+    return dict(value=1.0 / (ddim_steps * dt), unit="images/sec", cores=os.cpu_count(), kind="port",
+                sample=f"1 of {ddim_steps} DDIM steps of one 512x512 image (CFG pair) = {dt:.1f} s on the host cores, "
+                       f"NumPy/OpenBLAS fp32; extrapolated x{ddim_steps}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed passes (each = one 50-step sampling of the batch)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--stream-f32", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the pdengine hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from prompt_diffusion_amd import engine as E
+    from prompt_diffusion_amd import weights as W
+    from prompt_diffusion_amd.dist import shard_batch, all_gather_latents
+
+    cfg = W.SD15
+    B, S = args.batch, args.ddim_steps
+    h = w = args.size // 8
+    eng = E.Engine(cfg, device=local, precision=args.precision, stream_f32=args.stream_f32)
+    eng.init_random_weights(1234 + rank)
+
+    gen = torch.Generator(device=dev).manual_seed(2023 + rank)
+    x_T = torch.randn((B, 4, h, w), generator=gen, device=dev)
+    ctx_c = torch.randn((B, cfg.context_len, cfg.context_dim), generator=gen, device=dev)
+    ctx_u = torch.randn((B, cfg.context_len, cfg.context_dim), generator=gen, device=dev)
+    pair = torch.rand((B, 6, 8 * h, 8 * w), generator=gen, device=dev) * 2 - 1
+    query = torch.rand((B, 3, 8 * h, 8 * w), generator=gen, device=dev) * 2 - 1
+    kw = dict(x_T=x_T, ctx_cond=ctx_c, ctx_uncond=ctx_u, pair=pair, query=query, steps=S, cfg_scale=7.5, eta=0.0)
+
+    def one_pass():
+        lat = eng.ddim_sample(**kw)          # blocking: stream-synchronised on return
+        if world > 1:
+            lat = all_gather_latents(lat)    # the path's only exchange: final latents over RCCL/xGMI
+        return lat
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(out).all(), "non-finite latents"
+    images = world * B * args.steps
+    value = images / dt
+
+    result = {
+        "metric": "images/sec @ 512x512, 50-step DDIM, bs=8", "value": value, "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"SD1.5 UNet + Prompt-Diffusion ControlNet, {args.size}x{args.size}, {S}-step DDIM (eta 0), "
+                               f"CFG 7.5, bs={B} per GPU (forward batch {2 * B}), random-init weights",
+                   "global_batch": world * B, "latent": [h, w], "ddim_steps": S, "parallelism": f"batch-shard x{world}",
+                   "stream_f32": bool(args.stream_f32)},
+    }
+    if rank == 0:
+        # whole-path MFMA fraction against the algorithmic (hoisted) FLOP count of SURVEY.md §8d
+        gf_fwd = GF_PER_FWD_SAMPLE_64 * (h * w) / 4096.0 if (h, w) != (64, 64) else GF_PER_FWD_SAMPLE_64
+        tflop_image = 2 * S * gf_fwd / 1e3
+        result["path_tflops_per_gpu"] = value / world * tflop_image
+        if not args.no_profile:
+            # one more pass with HIP events around every contraction launch (not part of the timed region)
+            eng.set_option("profile", 1)
+            eng.ddim_sample(**kw)
+            peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+            classes = {}
+            for name, k in (("conv3x3_igemm", 0), ("linear_igemm", 1), ("attention", 2)):
+                ms, n, fl = eng.profile_read(k)
+                classes[name] = dict(ms=ms, launches=n, avg_us=1e3 * ms / max(n, 1), tflops=fl / max(ms, 1e-9) / 1e9)
+            eng.set_option("profile", 0)
+            ms0, n0, fl0 = eng.profile_read(-1)
+            ms_g = classes["conv3x3_igemm"]["ms"] + classes["linear_igemm"]["ms"]
+            n_g = classes["conv3x3_igemm"]["launches"] + classes["linear_igemm"]["launches"]
+            fl_g = (classes["conv3x3_igemm"]["tflops"] * classes["conv3x3_igemm"]["ms"] +
+                    classes["linear_igemm"]["tflops"] * classes["linear_igemm"]["ms"])
+            achieved = fl_g / max(ms_g, 1e-9)
+            result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3 + conv1x1/linear implicit GEMM)",
+                                  "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                                  "traffic": None, "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,
+                                  "device_ms_per_pass": ms_g, "by_class": classes}
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

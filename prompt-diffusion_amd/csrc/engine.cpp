@@ -300,6 +300,11 @@ int pd_engine::build() {
         pd_set_error("config yields %zu control tensors; at most %d supported", cnet.enc.size() + 1, PD_NUM_CONTROL);
         return 1;
     }
+    {
+        // initial workspace (per-op hooks, split-K slabs before the first session); sessions grow it
+        void* p = nullptr;
+        if (hipMalloc(&p, 256u << 20) == hipSuccess) { arena.base = reinterpret_cast<char*>(p); arena.cap = 256u << 20; }
+    }
     gn_partial_cap = 8u << 20;
     gn_partial = reinterpret_cast<double*>(dmalloc(gn_partial_cap));
     for (void* p : owned)
@@ -466,6 +471,27 @@ int pd_engine::init_random(uint64_t seed) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------ profiling
+hipEvent_t pd_engine::next_event() {
+    if (ev_used == ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ev_pool.push_back(e);
+    }
+    return ev_pool[ev_used++];
+}
+void pd_engine::prof_begin(ProfRec& r, int klass, double flops) {
+    r.klass = klass;
+    r.flops = flops;
+    r.a = next_event();
+    if (r.a) (void)hipEventRecord(r.a, stream);
+}
+void pd_engine::prof_end(ProfRec& r) {
+    r.b = next_event();
+    if (r.b) (void)hipEventRecord(r.b, stream);
+    prof.push_back(r);
+}
+
 // ------------------------------------------------------------------------------------ primitive ops
 Act pd_engine::new_act(int B, int H, int W, int C, int dt) {
     Act a;
@@ -480,7 +506,6 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         pd_set_error("gemm: input has %d channels, layer expects %d", in.C, m.cin_pad);
         return 1;
     }
-    if (arena.dry) return 0;
     GemmParams p{};
     p.A = in.p; p.W = m.w; p.bias = m.bias; p.C = out.p;
     p.R = R ? R->p : nullptr;
@@ -502,15 +527,46 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.vt_ld = vt_ld;
     p.Nout = m.Nout;
     p.splitk = 1;
+    p.slab = nullptr;
+    // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
+    const bool use_patch = opt_patch && conv_patch_tiles(p, f32) >= 192;
+    // otherwise split K when the tile grid cannot fill the chip (8x8 / 16x16 levels, time-embedding GEMMs)
+    if (!use_patch) {
+        const size_t mk = arena.mark();
+        const int tiles = gemm_tiles(p.M, m.N);
+        const int ktiles = m.Kpad / (128 / (int)dt_size(T));
+        int splitk = 1;
+        if (!m.geglu && !VT && tiles < 384 && ktiles >= 16 && m.N % 4 == 0) {
+            splitk = (512 + tiles - 1) / tiles;
+            if (splitk > ktiles / 8) splitk = ktiles / 8;
+            if (splitk > 8) splitk = 8;
+            if (splitk < 1) splitk = 1;
+        }
+        if (splitk > 1) {
+            p.slab = arena.alloc((size_t)splitk * p.M * m.N * sizeof(float));
+            if (!arena.dry && arena.top > arena.cap) { splitk = 1; p.slab = nullptr; }  // no room (op hooks outside a session)
+        }
+        p.splitk = splitk;
+        arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
+    }
+    if (arena.dry) return 0;
     if (f32 && in.dt != DT_F32) {
         pd_set_error("gemm: fp32 mode needs fp32 activations");
         return 1;
     }
     ++launches;
-    if (launch_gemm(p, f32, stream)) {
+    ProfRec rec{};
+    if (profiling) {
+        // algorithmic flops: 2 * M * N * K with the logical (unpadded) channel counts
+        const double n_log = m.geglu ? 2.0 * m.Nout : (double)m.Nout;
+        prof_begin(rec, m.taps == 9 ? 0 : 1, 2.0 * (double)p.M * n_log * (double)m.taps * (double)m.cin);
+        rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.taps * 10 + p.stride + (p.ups ? 5 : 0);
+    }
+    if (use_patch ? launch_conv_patch(p, f32, stream) : launch_gemm(p, f32, stream)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;
     }
+    if (profiling) prof_end(rec);
     return 0;
 }
 
@@ -559,7 +615,13 @@ int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const v
     p.scale = (float)(1.0 / std::sqrt((double)p.dh));
     p.B = B;
     ++launches;
+    ProfRec rec{};
+    if (profiling) {
+        prof_begin(rec, 2, 4.0 * (double)B * cfg.num_heads * (double)Nq * (double)Nk * (double)p.dh);
+        rec.M = Nq; rec.N = Nk; rec.K = p.dh; rec.taps = B;
+    }
     const int r = launch_attention(p, f32, stream);
+    if (profiling) prof_end(rec);
     if (r) {
         pd_set_error(r == 2 ? "attention: unsupported head dim %d" : "attention launch failed (dh %d)", p.dh);
         return 1;

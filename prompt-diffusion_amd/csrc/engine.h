@@ -178,7 +178,17 @@ struct pd_engine {
     Arena arena;
     Session ses;
     int verbose = 0;
+    bool opt_patch = true;  // use the LDS-patch conv3x3 kernel where eligible
     long long launches = 0;
+    // optional per-launch timing (bench.py roofline leg): HIP events around every contraction launch
+    struct ProfRec { hipEvent_t a, b; int klass; double flops; int M, N, K, taps; };
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t next_event();
+    void prof_begin(ProfRec& r, int klass, double flops);
+    void prof_end(ProfRec& r);
     double* gn_partial = nullptr;  // scratch for GroupNorm partial sums
     size_t gn_partial_cap = 0;
 

@@ -5,16 +5,23 @@
 //   M = B*Hout*Wout output pixels / tokens (NHWC rows), N = Cout, K = taps*Cin.
 // Tile: 128(M) x 160(N) x 128 bytes of K per step, 256 threads = 4 waves.  160 divides every channel
 // count of SD1.5 (320/640/960/1280/1920/2560/5120/10240), so no N padding is wasted.
-// Operands are staged global -> VGPR -> LDS (the A gather needs per-row halo masks, so no LDS-DMA),
-// double-buffered, one barrier per K step; LDS rows are 128 B with a 16-B-chunk XOR swizzle
-// (chunk ^= (row>>1)&7) that makes the ds_read_b128 fragment reads conflict-free.
+// Operands are staged global -> VGPR -> LDS (the A gather needs per-row halo masks), double-buffered,
+// one barrier per K step.  All global loads of a K step are issued back to back with NO divergent
+// control flow around them (out-of-image / out-of-range rows load a clamped address and are zeroed by
+// a select), so the whole step's 9 x 16 B per lane is in flight under the previous step's MFMAs.
+// LDS rows are 128 B with a 16-B-chunk XOR swizzle (chunk ^= (row>>1)&7) that makes the ds_read_b128
+// fragment reads conflict-free.
 // The MFMA is issued "swapped" (weights as the A operand, activations as B) so every lane ends up with
 // 4 consecutive output channels of one pixel: bias/residual/time-embedding reads and the store are
 // 8-16 B vectors along the NHWC channel axis.
 // Precision modes share the byte-level data path: bf16 -> v_mfma_f32_16x16x32_bf16 (8 k per lane),
 // fp32 -> 4 x v_mfma_f32_16x16x4_f32 on the same 16-byte fragment (k order permuted identically on
 // both operands, which leaves the dot product unchanged).
+// Small-M layers (the 8x8 and 16x16 levels) split K across blockIdx.y: each slice writes an fp32 slab
+// with plain stores and splitk_finalize_kernel sums the slabs in slice order (deterministic) and applies
+// the epilogue.
 #include "pd_common.h"
+#include "pd_mma.h"
 
 namespace {
 
@@ -26,42 +33,16 @@ constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row * BKB) + (((chunk ^ (row >> 1)) & 7) << 4); }
 
-template <bool F32>
-__device__ __forceinline__ void mma(const uint4& w, const uint4& a, f32x4& acc) {
-    if constexpr (F32) {
-        const float* wf = reinterpret_cast<const float*>(&w);
-        const float* af = reinterpret_cast<const float*>(&a);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[j], acc, 0, 0, 0);
-    } else {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a),
-                                                      acc, 0, 0, 0);
-    }
-}
-
-// convert 8 fp32 (two uint4) to 8 bf16 (one uint4)
-__device__ __forceinline__ uint4 cvt8(const uint4& lo, const uint4& hi, bool do_silu) {
-    float f[8];
-    const float* a = reinterpret_cast<const float*>(&lo);
-    const float* b = reinterpret_cast<const float*>(&hi);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
-    if (do_silu) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
-    }
-    uint4 r;
-    r.x = pack2bf(f[0], f[1]); r.y = pack2bf(f[2], f[3]); r.z = pack2bf(f[4], f[5]); r.w = pack2bf(f[6], f[7]);
-    return r;
-}
-
-template <bool F32, int WM, int WN>
+// F32: fp32 MFMA mode.  CONV: 3x3 gather (else rows of A are contiguous).  AF32: bf16 compute with an
+// fp32 A source (converted while staging; only meaningful when !F32).
+template <bool F32, int WM, int WN, bool CONV, bool AF32>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
     constexpr int EB = F32 ? 4 : 2;
     constexpr int VEC = 16 / EB;    // elements per 16-byte chunk
     constexpr int BKE = BKB / EB;   // elements of K per step
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MT = WTM / 16, NT = WTN / 16;
+    constexpr int AEB = (F32 || AF32) ? 4 : 2;  // bytes per element of the A source
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -84,7 +65,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
     // ---- per-thread staging assignment
     const int chunk = tid & 7;
     const int row0 = tid >> 3;  // + 32*i
-    int a_b[A_ITERS], a_y[A_ITERS], a_x[A_ITERS];
+    int a_pix[A_ITERS];         // CONV: sample * Hin (row base); else unused
+    int a_y[A_ITERS], a_x[A_ITERS];
     bool a_ok[A_ITERS];
     size_t a_base[A_ITERS];
 #pragma unroll
@@ -92,25 +74,25 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
         const int m = bm * BM + row0 + 32 * i;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
-        if (p.taps == 1) {
-            a_base[i] = (size_t)mm * p.lda;
-            a_b[i] = a_y[i] = a_x[i] = 0;
-        } else {
+        if constexpr (CONV) {
             const int b = mm / p.rows_per_sample;
             const int rem = mm - b * p.rows_per_sample;
             const int oy = rem / p.Wout;
-            a_b[i] = b;
+            a_pix[i] = b * p.Hin;
             a_y[i] = oy * p.stride - 1;
             a_x[i] = (rem - oy * p.Wout) * p.stride - 1;
             a_base[i] = 0;
+        } else {
+            a_base[i] = (size_t)mm * p.lda;
+            a_pix[i] = a_y[i] = a_x[i] = 0;
         }
     }
-    size_t w_base[B_ITERS];
+    const char* w_ptr[B_ITERS];
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
         int n = bn * BN + row0 + 32 * i;
         n = n < p.N ? n : p.N - 1;  // clamp: columns >= N are never stored
-        w_base[i] = (size_t)n * p.Kpad;
+        w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)n * p.Kpad + chunk * VEC) * EB;
     }
 
     const int ktiles_all = p.Kpad / BKE;
@@ -121,15 +103,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
         kt1 = min(ktiles_all, kt0 + per);
     }
 
-    uint4 ra[A_ITERS], rb[B_ITERS];
+    uint4 ra[A_ITERS][AEB == 4 && !F32 ? 2 : 1], rb[B_ITERS];
+    bool rok[A_ITERS];
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-    const bool a_f32 = p.a_dt == DT_F32;
+    const char* Ab = reinterpret_cast<const char*>(p.A);
 
+    // issue every global load of K step kt; nothing here branches per lane
     auto gload = [&](int kt) {
         const int k0 = kt * BKE + chunk * VEC;
         const bool kok = k0 < p.K;
         int ky = 0, kx = 0, cof = k0;
-        if (p.taps != 1) {
+        if constexpr (CONV) {
             const int tap = k0 / p.Cin;
             cof = k0 - tap * p.Cin;
             ky = tap / 3;
@@ -139,42 +123,45 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
         for (int i = 0; i < A_ITERS; ++i) {
             bool ok = a_ok[i] && kok;
             size_t idx;
-            if (p.taps == 1) {
-                idx = a_base[i] + cof;
-            } else {
+            if constexpr (CONV) {
                 const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-                ok = ok && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-                idx = ((size_t)(a_b[i] * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) * p.lda + cof;
+                ok = ok && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                const int pix = (a_pix[i] + (iy >> p.ups)) * p.Win + (ix >> p.ups);
+                idx = (size_t)(ok ? pix : 0) * p.lda + cof;
+            } else {
+                idx = a_base[i] + cof;
             }
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                if constexpr (F32) {
-                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p.A) + idx);
-                    if (p.a_silu) {
-                        float* f = reinterpret_cast<float*>(&v);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
-                    }
-                } else if (a_f32) {
-                    const uint4* s = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p.A) + idx);
-                    v = cvt8(s[0], s[1], p.a_silu != 0);
-                } else {
-                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.A) + idx);
-                }
-            }
-            ra[i] = v;
+            idx = ok ? idx : 0;
+            rok[i] = ok;
+            const uint4* s = reinterpret_cast<const uint4*>(Ab + idx * AEB);
+            ra[i][0] = s[0];
+            if constexpr (AEB == 4 && !F32) ra[i][1] = s[1];
         }
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            rb[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.W) +
-                                                    (w_base[i] + (size_t)kt * BKE + chunk * VEC) * EB);
-        }
+        for (int i = 0; i < B_ITERS; ++i)
+            rb[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + (size_t)kt * BKE * EB);
     };
     auto lstore = [&](int buf) {
         char* sa = smem + buf * (BM + BN) * BKB;
         char* sb = sa + BM * BKB;
 #pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<uint4*>(sa + swz(row0 + 32 * i, chunk)) = ra[i];
+        for (int i = 0; i < A_ITERS; ++i) {
+            uint4 v;
+            if constexpr (F32) {
+                v = ra[i][0];
+                if (p.a_silu) {
+                    float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
+                }
+            } else if constexpr (AF32) {
+                v = cvt8(ra[i][0], ra[i][1], p.a_silu != 0);
+            } else {
+                v = ra[i][0];
+            }
+            if (!rok[i]) v = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(sa + swz(row0 + 32 * i, chunk)) = v;
+        }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<uint4*>(sb + swz(row0 + 32 * i, chunk)) = rb[i];
     };
@@ -194,7 +181,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) gload(kt + 1);
+        const bool more = kt + 1 < kt1;
+        if (more) gload(kt + 1);
         const char* sa = smem + buf * (BM + BN) * BKB;
         const char* sb = sa + BM * BKB;
 #pragma unroll
@@ -209,13 +197,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) mma<F32>(wf[n], af[m], acc[n][m]);
         }
-        if (kt + 1 < kt1) lstore(buf ^ 1);
+        if (more) lstore(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: lane holds channels n..n+3 (rows of the swapped MFMA) of pixel m
     if (p.splitk > 1) {
-        float* Cf = reinterpret_cast<float*>(p.C);
+        float* slab = reinterpret_cast<float*>(p.slab) + (size_t)kslice * p.M * p.N;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int gm = bm * BM + wm * WTM + m * 16 + fr;
@@ -224,8 +212,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
             for (int n = 0; n < NT; ++n) {
                 const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
                 if (gn >= p.N) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) atomicAdd(Cf + (size_t)gm * p.ldc + gn + j, acc[n][m][j]);
+                *reinterpret_cast<f32x4*>(slab + (size_t)gm * p.N + gn) = acc[n][m];
             }
         }
         return;
@@ -261,38 +248,30 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
         for (int n = 0; n < NT; ++n) {
             const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
             if (gn >= p.N) continue;
-            f32x4 v = acc[n][m];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + gn);
-            if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (size_t)sample * p.rowvec_stride + gn);
-            if (p.act == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-            }
-            v *= p.out_scale;
-            if (p.R) v += load4(p.R, (size_t)gm * p.ldr + gn, p.r_dt);
-            if (gn >= p.vt_begin) {
-                // transposed store (attention V^T): [sample][channel][token]
-                const size_t base = ((size_t)sample * (p.N - p.vt_begin) + (gn - p.vt_begin)) * p.vt_ld + tok;
-                if (p.c_dt == DT_F32) {
-                    float* o = reinterpret_cast<float*>(p.VT);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[base + (size_t)j * p.vt_ld] = v[j];
-                } else {
-                    uint16_t* o = reinterpret_cast<uint16_t*>(p.VT);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[base + (size_t)j * p.vt_ld] = f2bf(v[j]);
-                }
-            } else {
-                store4(p.C, (size_t)gm * p.ldc + gn, p.c_dt, v);
-            }
+            epilogue4(p, gm, gn, sample, tok, acc[n][m]);
         }
     }
 }
 
-template <bool F32, int WM, int WN>
+// sums the split-K slabs in slice order and applies the epilogue; one thread per 4 channels
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
+    const int n4 = p.N / 4;
+    const long long total = (long long)p.M * n4;
+    const float* slab = reinterpret_cast<const float*>(p.slab);
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int gm = (int)(i / n4);
+        const int gn = (int)(i - (long long)gm * n4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + (size_t)gm * p.N + gn);
+        for (int s = 1; s < p.splitk; ++s) v += *reinterpret_cast<const f32x4*>(slab + ((size_t)s * p.M + gm) * p.N + gn);
+        const int sample = gm / p.rows_per_sample;
+        epilogue4(p, gm, gn, sample, gm - sample * p.rows_per_sample, v);
+    }
+}
+
+template <bool F32, int WM, int WN, bool CONV, bool AF32>
 int launch_one(const GemmParams& p, hipStream_t s) {
     static bool attr_done = false;
-    auto kfn = igemm_kernel<F32, WM, WN>;
+    auto kfn = igemm_kernel<F32, WM, WN, CONV, AF32>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SMEM_BYTES) != hipSuccess)
@@ -302,13 +281,31 @@ int launch_one(const GemmParams& p, hipStream_t s) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
     dim3 grid(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    if (hipGetLastError() != hipSuccess) return 1;
+    if (p.splitk > 1) {
+        long long total = (long long)p.M * (p.N / 4);
+        int nb = (int)((total + 255) / 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3(nb), dim3(256), 0, s, p);
+        if (hipGetLastError() != hipSuccess) return 1;
+    }
+    return 0;
 }
 
 }  // namespace
 
+int gemm_tiles(int M, int N) { return ((M + BM - 1) / BM) * ((N + BN - 1) / BN); }
+
 int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return 0;
-    if (p.act == 2) return f32mode ? launch_one<true, 4, 1>(p, s) : launch_one<false, 4, 1>(p, s);
-    return f32mode ? launch_one<true, 2, 2>(p, s) : launch_one<false, 2, 2>(p, s);
+    const bool conv = p.taps != 1;
+    const bool af32 = p.a_dt == DT_F32;
+    if (p.splitk > 1 && (p.act == 2 || p.vt_begin < p.N || !p.slab || p.N % 4)) return 1;
+    if (p.act == 2) {
+        if (conv || (!f32mode && af32)) return 1;
+        return f32mode ? launch_one<true, 4, 1, false, false>(p, s) : launch_one<false, 4, 1, false, false>(p, s);
+    }
+    if (f32mode) return conv ? launch_one<true, 2, 2, true, false>(p, s) : launch_one<true, 2, 2, false, false>(p, s);
+    if (conv) return af32 ? launch_one<false, 2, 2, true, true>(p, s) : launch_one<false, 2, 2, true, false>(p, s);
+    return af32 ? launch_one<false, 2, 2, false, true>(p, s) : launch_one<false, 2, 2, false, false>(p, s);
 }

@@ -73,7 +73,8 @@ struct GemmParams {
     float out_scale;      // applied to (acc + bias [+ rowvec]) before the residual
     int vt_begin, vt_ld;  // see VT
     int Nout;             // GEGLU: logical output columns (N/2 rounded), else == N
-    int splitk;           // >1: grid.y slices K; partial sums atomically added into fp32 C (epilogue by a second pass)
+    int splitk;           // >1: grid.y slices K; each slice stores an fp32 slab, a finalize pass sums them + epilogue
+    void* slab;           // [splitk][M][N] fp32 workspace
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
@@ -88,6 +89,9 @@ struct AttnParams {
 };
 
 int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s);
+int gemm_tiles(int M, int N);
+int conv_patch_tiles(const GemmParams& p, bool f32mode);  // 0: shape not eligible for the LDS-patch conv kernel
+int launch_conv_patch(const GemmParams& p, bool f32mode, hipStream_t s);
 int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s);
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,

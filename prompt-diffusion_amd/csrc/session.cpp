@@ -567,6 +567,14 @@ void* pd_stream(pd_engine* e) { return e ? (void*)e->stream : nullptr; }
 int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!e || !key) { pd_set_error("null argument"); return 1; }
     if (!strcmp(key, "verbose")) { e->verbose = (int)value; return 0; }
+    if (!strcmp(key, "conv_patch")) { e->opt_patch = value != 0; return 0; }
+    if (!strcmp(key, "profile")) {
+        (void)hipStreamSynchronize(e->stream);
+        e->profiling = value != 0;
+        e->prof.clear();
+        e->ev_used = 0;
+        return 0;
+    }
     pd_set_error("unknown option '%s'", key);
     return 1;
 }
@@ -578,6 +586,40 @@ int64_t pd_get_stat(pd_engine* e, const char* key) {
     if (!strcmp(key, "launches")) return (int64_t)e->launches;
     if (!strcmp(key, "steps")) return (int64_t)e->ses.S;
     return -1;
+}
+
+// Per-launch HIP-event timing collected while option "profile" is on.  klass: 0 conv3x3 implicit GEMM,
+// 1 conv1x1 / linear GEMM, 2 attention, -1 all.
+int pd_profile_read(pd_engine* e, int32_t klass, double* total_ms, int64_t* n_launches, double* flops) {
+    if (!e) { pd_set_error("null engine"); return 1; }
+    HIP_OK(hipStreamSynchronize(e->stream));
+    double ms = 0.0, fl = 0.0;
+    int64_t n = 0;
+    for (auto& r : e->prof) {
+        if (klass >= 0 && r.klass != klass) continue;
+        float t = 0.f;
+        if (r.a && r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; fl += r.flops; ++n; }
+    }
+    if (total_ms) *total_ms = ms;
+    if (n_launches) *n_launches = n;
+    if (flops) *flops = fl;
+    return 0;
+}
+
+// Debug aid: one CSV row per profiled launch (klass, M, N, K, taps-code, ms, flops).
+int pd_profile_dump(pd_engine* e, const char* path) {
+    if (!e || !path) { pd_set_error("null argument"); return 1; }
+    HIP_OK(hipStreamSynchronize(e->stream));
+    FILE* f = fopen(path, "w");
+    if (!f) { pd_set_error("cannot open %s", path); return 1; }
+    fprintf(f, "klass,M,N,K,taps,ms,flops\n");
+    for (auto& r : e->prof) {
+        float t = 0.f;
+        if (r.a && r.b && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess)
+            fprintf(f, "%d,%d,%d,%d,%d,%.6f,%.0f\n", r.klass, r.M, r.N, r.K, r.taps, t, r.flops);
+    }
+    fclose(f);
+    return 0;
 }
 
 int pd_bench_conv3x3(pd_engine* e, int32_t Bf, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t iters, float* ms) {

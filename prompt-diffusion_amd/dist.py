@@ -1,0 +1,59 @@
+"""Batch sharding across the GPUs of one node.
+
+Every image is independent through all denoising steps (GroupNorm/LayerNorm are per-sample, a CFG pair
+stays on one GPU), so the path shards with NO per-step exchange -- exactly how the reference shards
+sampling (``batch_ids = np.arange(100)[rank::world_size]``, eval/evaluate_gen.py:55-57).  The only
+collective is one all-gather of the final latents (RCCL over xGMI: backend "nccl" on ROCm; "gloo" in the
+CPU tests).  One process per GPU.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of n items: the first n % world ranks get one extra."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(inputs: Dict[str, "np.ndarray"], rank: int, world: int) -> Dict[str, "np.ndarray"]:
+    """Slice every batch-major input ([B, ...]) to this rank's contiguous shard."""
+    n = next(iter(inputs.values())).shape[0]
+    lo, hi = shard_range(n, rank, world)
+    return {k: (v[lo:hi] if v is not None else None) for k, v in inputs.items()}
+
+
+def all_gather_latents(latents, group=None):
+    """Gather [b_r, C, h, w] shards from every rank into [sum b_r, C, h, w] (rank order = batch order).
+
+    Equal shards use one all_gather_into_tensor (a single direct RCCL all-gather: <= 4 MB total at
+    bs=64, latency-bound); ragged shards are padded to the largest and trimmed."""
+    import torch
+    import torch.distributed as dist
+    t = latents if isinstance(latents, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(latents))
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    if t.shape[0] < mx:
+        pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad])
+    t = t.contiguous()
+    out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if dist.get_backend(group) == "gloo":
+        parts = list(out.chunk(world))
+        dist.all_gather(parts, t, group=group)
+        out = torch.cat(parts)
+    else:
+        dist.all_gather_into_tensor(out, t, group=group)
+    if all(s == mx for s in sizes):
+        return out
+    return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)])

@@ -95,6 +95,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_get_stat.argtypes = [C.c_void_p, C.c_char_p]
     lib.pd_get_stat.restype = C.c_int64
     lib.pd_bench_conv3x3.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float)]
+    lib.pd_profile_dump.argtypes = [C.c_void_p, C.c_char_p]
+    lib.pd_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     # per-op parity hooks (include/pdengine_ops.h)
     fp = C.c_void_p
     lib.pd_op_conv2d.argtypes = [C.c_void_p, fp, fp, fp, fp] + [C.c_int] * 9 + [C.c_float, C.c_int, fp]
@@ -112,6 +114,7 @@ EXPORTS = [
     "pd_load_weights", "pd_init_random_weights", "pd_weights_missing", "pd_eps", "pd_control_shape", "pd_ddim_sample",
     "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_eps_at", "pd_sample_end",
     "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3",
+    "pd_profile_read", "pd_profile_dump",
     "pd_op_conv2d", "pd_op_linear", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention",
 ]
 
@@ -381,6 +384,15 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self.lib.pd_set_option(self._h, key.encode(), int(value)))
+
+    def profile_read(self, klass: int = -1) -> Tuple[float, int, float]:
+        """(device ms, launches, algorithmic FLOPs) of the launches bracketed while option 'profile' was on."""
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.pd_profile_read(self._h, klass, C.byref(ms), C.byref(n), C.byref(fl)))
+        return float(ms.value), int(n.value), float(fl.value)
+
+    def profile_dump(self, path: str) -> None:
+        self._check(self.lib.pd_profile_dump(self._h, path.encode()))
 
     def bench_conv3x3(self, Bf: int, H: int, W: int, Cin: int, Cout: int, iters: int = 20) -> float:
         ms = C.c_float()

@@ -39,6 +39,9 @@ def rng(seed):
     (3, 320, 16, 16, 320, 3, 1, False),  # SD1.5 shape, N = 2 x 160 tiles, M = 768
     (1, 320, 8, 8, 4, 3, 1, False),      # out conv: N = 4
     (1, 200, 5, 5, 168, 3, 1, False),    # ragged M and N tiles, Cin not a multiple of the K tile
+    (12, 64, 32, 32, 320, 3, 1, False),  # LDS-patch kernel: 48 patches x 2 n-tiles... (>=192 blocks: 12*4*4)
+    (13, 128, 16, 48, 168, 3, 1, False), # LDS-patch kernel, non-square, ragged N tile
+    (50, 64, 16, 16, 96, 3, 1, True),    # LDS-patch kernel with fused nearest-x2 upsample (input 16x16 -> 32x32)
 ])
 def test_conv2d(eng, B, Cin, H, W, Cout, k, stride, ups):
     g = rng(1)
