@@ -547,6 +547,8 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
             if (!arena.dry && arena.top > arena.cap) { splitk = 1; p.slab = nullptr; }  // no room (op hooks outside a session)
         }
         p.splitk = splitk;
+        // 256-row tiles when they still give every CU a block (1 block of 8 waves per CU)
+        p.big_tile = (opt_bigtile && splitk == 1 && ((p.M + 255) / 256) * ((m.N + 159) / 160) >= 256) ? 1 : 0;
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
     }
     if (arena.dry) return 0;

@@ -25,18 +25,20 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 160, BKB = 128;  // tile; BKB = bytes of K per LDS row
-constexpr int NTHREADS = 256;
-constexpr int A_ITERS = BM * 8 / NTHREADS;  // 16-byte chunks per thread per K step (4)
-constexpr int B_ITERS = BN * 8 / NTHREADS;  // (5)
-constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB;
+constexpr int BN = 160, BKB = 128;  // tile columns; BKB = bytes of K per LDS row
+// Two block shapes: 128 x 160 with 4 waves (2 blocks per CU) and 256 x 160 with 8 waves (1 block per CU,
+// 1.4x fewer operand bytes per FLOP) for layers with enough rows to fill the chip with the big tile.
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row * BKB) + (((chunk ^ (row >> 1)) & 7) << 4); }
 
 // F32: fp32 MFMA mode.  CONV: 3x3 gather (else rows of A are contiguous).  AF32: bf16 compute with an
 // fp32 A source (converted while staging; only meaningful when !F32).
-template <bool F32, int WM, int WN, bool CONV, bool AF32>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
+template <bool F32, int BM, int WM, int WN, bool CONV, bool AF32>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(GemmParams p) {
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int A_ITERS = BM * 8 / NTHREADS;                   // 16-byte chunks per thread per K step
+    constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;  // last one masked when it does not divide
+    constexpr int ROWS_PER_IT = NTHREADS / 8;
     constexpr int EB = F32 ? 4 : 2;
     constexpr int VEC = 16 / EB;    // elements per 16-byte chunk
     constexpr int BKE = BKB / EB;   // elements of K per step
@@ -64,14 +66,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
 
     // ---- per-thread staging assignment
     const int chunk = tid & 7;
-    const int row0 = tid >> 3;  // + 32*i
+    const int row0 = tid >> 3;  // + ROWS_PER_IT*i
     int a_pix[A_ITERS];         // CONV: sample * Hin (row base); else unused
     int a_y[A_ITERS], a_x[A_ITERS];
     bool a_ok[A_ITERS];
     size_t a_base[A_ITERS];
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-        const int m = bm * BM + row0 + 32 * i;
+        const int m = bm * BM + row0 + ROWS_PER_IT * i;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
         if constexpr (CONV) {
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
     const char* w_ptr[B_ITERS];
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-        int n = bn * BN + row0 + 32 * i;
+        int n = bn * BN + row0 + ROWS_PER_IT * i;
         n = n < p.N ? n : p.N - 1;  // clamp: columns >= N are never stored
         w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)n * p.Kpad + chunk * VEC) * EB;
     }
@@ -103,13 +105,29 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
         kt1 = min(ktiles_all, kt0 + per);
     }
 
-    uint4 ra[A_ITERS][AEB == 4 && !F32 ? 2 : 1], rb[B_ITERS];
-    bool rok[A_ITERS];
+    // Staging registers are NAMED scalars reached through constexpr selectors: hipcc leaves small indexed
+    // arrays captured by these lambdas in scratch memory, which serialises every prefetch behind a wait.
+    static_assert(A_ITERS <= 4 && B_ITERS <= 5, "staging registers below cover 4 A and 5 B pieces");
+    uint4 ra0, ra1, ra2, ra3, rh0, rh1, rh2, rh3, rb0, rb1, rb2, rb3, rb4;
+    auto RA = [&](auto I) __attribute__((always_inline)) -> uint4& {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i == 0) return ra0; else if constexpr (i == 1) return ra1; else if constexpr (i == 2) return ra2; else return ra3;
+    };
+    auto RH = [&](auto I) __attribute__((always_inline)) -> uint4& {  // second 16 B of an fp32 A source (AF32)
+        constexpr int i = decltype(I)::value;
+        if constexpr (i == 0) return rh0; else if constexpr (i == 1) return rh1; else if constexpr (i == 2) return rh2; else return rh3;
+    };
+    auto RB = [&](auto I) __attribute__((always_inline)) -> uint4& {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i == 0) return rb0; else if constexpr (i == 1) return rb1; else if constexpr (i == 2) return rb2;
+        else if constexpr (i == 3) return rb3; else return rb4;
+    };
+    unsigned rokmask = 0;
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
     const char* Ab = reinterpret_cast<const char*>(p.A);
 
     // issue every global load of K step kt; nothing here branches per lane
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt) __attribute__((always_inline)) {
         const int k0 = kt * BKE + chunk * VEC;
         const bool kok = k0 < p.K;
         int ky = 0, kx = 0, cof = k0;
@@ -119,8 +137,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
             ky = tap / 3;
             kx = tap - ky * 3;
         }
-#pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) {
+        rokmask = 0;
+        static_for<A_ITERS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
             bool ok = a_ok[i] && kok;
             size_t idx;
             if constexpr (CONV) {
@@ -132,38 +151,42 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(GemmParams p) {
                 idx = a_base[i] + cof;
             }
             idx = ok ? idx : 0;
-            rok[i] = ok;
+            rokmask |= ok ? (1u << i) : 0u;
             const uint4* s = reinterpret_cast<const uint4*>(Ab + idx * AEB);
-            ra[i][0] = s[0];
-            if constexpr (AEB == 4 && !F32) ra[i][1] = s[1];
-        }
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i)
-            rb[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + (size_t)kt * BKE * EB);
+            RA(I) = s[0];
+            if constexpr (AEB == 4 && !F32) RH(I) = s[1];
+        });
+        static_for<B_ITERS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            RB(I) = *reinterpret_cast<const uint4*>(w_ptr[i] + (size_t)kt * BKE * EB);
+        });
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
         char* sa = smem + buf * (BM + BN) * BKB;
         char* sb = sa + BM * BKB;
-#pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) {
+        static_for<A_ITERS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
             uint4 v;
             if constexpr (F32) {
-                v = ra[i][0];
+                v = RA(I);
                 if (p.a_silu) {
                     float* f = reinterpret_cast<float*>(&v);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
                 }
             } else if constexpr (AF32) {
-                v = cvt8(ra[i][0], ra[i][1], p.a_silu != 0);
+                v = cvt8(RA(I), RH(I), p.a_silu != 0);
             } else {
-                v = ra[i][0];
+                v = RA(I);
             }
-            if (!rok[i]) v = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(sa + swz(row0 + 32 * i, chunk)) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) *reinterpret_cast<uint4*>(sb + swz(row0 + 32 * i, chunk)) = rb[i];
+            if (!(rokmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(sa + swz(row0 + ROWS_PER_IT * i, chunk)) = v;
+        });
+        static_for<B_ITERS>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if (BN % ROWS_PER_IT == 0 || row0 + ROWS_PER_IT * i < BN)
+                *reinterpret_cast<uint4*>(sb + swz(row0 + ROWS_PER_IT * i, chunk)) = RB(I);
+        });
     };
 
     f32x4 acc[NT][MT];
@@ -268,10 +291,12 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
     }
 }
 
-template <bool F32, int WM, int WN, bool CONV, bool AF32>
+template <bool F32, int BM, int WM, int WN, bool CONV, bool AF32>
 int launch_one(const GemmParams& p, hipStream_t s) {
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB;
     static bool attr_done = false;
-    auto kfn = igemm_kernel<F32, WM, WN, CONV, AF32>;
+    auto kfn = igemm_kernel<F32, BM, WM, WN, CONV, AF32>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SMEM_BYTES) != hipSuccess)
@@ -294,18 +319,26 @@ int launch_one(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-int gemm_tiles(int M, int N) { return ((M + BM - 1) / BM) * ((N + BN - 1) / BN); }
+int gemm_tiles(int M, int N) { return ((M + 127) / 128) * ((N + BN - 1) / BN); }
 
 int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return 0;
     const bool conv = p.taps != 1;
     const bool af32 = p.a_dt == DT_F32;
     if (p.splitk > 1 && (p.act == 2 || p.vt_begin < p.N || !p.slab || p.N % 4)) return 1;
+    // big tile when it still yields at least one block per CU
+    const bool big = p.big_tile && p.splitk == 1;
     if (p.act == 2) {
         if (conv || (!f32mode && af32)) return 1;
-        return f32mode ? launch_one<true, 4, 1, false, false>(p, s) : launch_one<false, 4, 1, false, false>(p, s);
+        if (big) return f32mode ? launch_one<true, 256, 8, 1, false, false>(p, s) : launch_one<false, 256, 8, 1, false, false>(p, s);
+        return f32mode ? launch_one<true, 128, 4, 1, false, false>(p, s) : launch_one<false, 128, 4, 1, false, false>(p, s);
     }
-    if (f32mode) return conv ? launch_one<true, 2, 2, true, false>(p, s) : launch_one<true, 2, 2, false, false>(p, s);
-    if (conv) return af32 ? launch_one<false, 2, 2, true, true>(p, s) : launch_one<false, 2, 2, true, false>(p, s);
-    return af32 ? launch_one<false, 2, 2, false, true>(p, s) : launch_one<false, 2, 2, false, false>(p, s);
+    if (big) {
+        if (f32mode) return conv ? launch_one<true, 256, 4, 2, true, false>(p, s) : launch_one<true, 256, 4, 2, false, false>(p, s);
+        if (conv) return af32 ? launch_one<false, 256, 4, 2, true, true>(p, s) : launch_one<false, 256, 4, 2, true, false>(p, s);
+        return af32 ? launch_one<false, 256, 4, 2, false, true>(p, s) : launch_one<false, 256, 4, 2, false, false>(p, s);
+    }
+    if (f32mode) return conv ? launch_one<true, 128, 2, 2, true, false>(p, s) : launch_one<true, 128, 2, 2, false, false>(p, s);
+    if (conv) return af32 ? launch_one<false, 128, 2, 2, true, true>(p, s) : launch_one<false, 128, 2, 2, true, false>(p, s);
+    return af32 ? launch_one<false, 128, 2, 2, false, true>(p, s) : launch_one<false, 128, 2, 2, false, false>(p, s);
 }

@@ -75,6 +75,7 @@ struct GemmParams {
     int Nout;             // GEGLU: logical output columns (N/2 rounded), else == N
     int splitk;           // >1: grid.y slices K; each slice stores an fp32 slab, a finalize pass sums them + epilogue
     void* slab;           // [splitk][M][N] fp32 workspace
+    int big_tile;         // 1: 256 x 160 block tile (8 waves) instead of 128 x 160
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)

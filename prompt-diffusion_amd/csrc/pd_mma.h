@@ -1,6 +1,19 @@
 // Device helpers shared by the contraction kernels (gemm.hip, conv_patch.hip).
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "pd_common.h"
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 template <bool F32>
 __device__ __forceinline__ void mma(const uint4& w, const uint4& a, f32x4& acc) {
