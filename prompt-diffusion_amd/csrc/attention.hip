@@ -15,6 +15,7 @@
 // goes through LDS, softmax row statistics are lane-local plus two cross-lane steps (xor 16, 32), and
 // the O^T rescale uses the lane's own alpha.
 #include "pd_common.h"
+#include "pd_mma.h"
 
 namespace {
 
@@ -224,6 +225,254 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 fast path (dh <= 80): same math and fragment mapping as attn_kernel, but the next K / V^T tile is
+// requested into registers BEFORE the current tile's MFMAs and written to the other LDS buffer after them
+// (one barrier per tile, global latency hidden), the softmax scale is folded into one FMA feeding
+// v_exp_f32, and key masking runs only on the ragged last tile.
+template <int DH>
+struct Attn2Cfg {
+    static constexpr int NCH = DH * 2 / 16;
+    static constexpr int KS = (NCH + 3) / 4;
+    static constexpr int NTD = (DH + 15) / 16;
+    static constexpr int KROW = KS * 64 + 16;
+    static constexpr int VROW = TK * 2 + 16;
+    static constexpr int K_BYTES = TK * KROW, V_BYTES = NTD * 16 * VROW;
+    static constexpr int K_SLOTS = TK * NCH;        // valid 16-byte chunks of a K tile
+    static constexpr int V_SLOTS = DH * 8;          // valid chunks of a V^T tile (8 per row of 64 keys)
+    static constexpr int K_IT = (K_SLOTS + 255) / 256, V_IT = (V_SLOTS + 255) / 256;
+    static constexpr int SMEM = 2 * (K_BYTES + V_BYTES);
+    static_assert(K_IT <= 3 && V_IT <= 3, "staging registers cover 3 + 3 pieces");
+};
+
+template <int DH>
+__global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnParams p) {
+    using Cfg = Attn2Cfg<DH>;
+    constexpr int NCH = Cfg::NCH, KS = Cfg::KS, NTD = Cfg::NTD, KROW = Cfg::KROW, VROW = Cfg::VROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int bh = blockIdx.y;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const char* Qb = reinterpret_cast<const char*>(p.Q) + ((size_t)b * p.q_bs + (size_t)h * DH) * 2;
+    const char* Kb = reinterpret_cast<const char*>(p.K) + ((size_t)b * p.k_bs + (size_t)h * DH) * 2;
+    const char* Vb = reinterpret_cast<const char*>(p.VT) + ((size_t)b * p.vt_bs + (size_t)h * DH * p.vt_ld) * 2;
+
+    uint4 qf[KS][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = q0 + qt * 16 + fr;
+        q = q < p.Nq ? q : p.Nq - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 4 + fq;
+            qf[ks][qt] = c < NCH ? *reinterpret_cast<const uint4*>(Qb + (size_t)q * p.ldq * 2 + c * 16) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // zero the pad chunks / pad rows of both LDS buffers once (they never change)
+    for (int i = tid; i < Cfg::SMEM / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    // staging registers (named: see gemm.hip) and their per-thread slots
+    uint4 kr0, kr1, kr2, vr0, vr1, vr2;
+    auto KR = [&](auto I) __attribute__((always_inline)) -> uint4& {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i == 0) return kr0; else if constexpr (i == 1) return kr1; else return kr2;
+    };
+    auto VR = [&](auto I) __attribute__((always_inline)) -> uint4& {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i == 0) return vr0; else if constexpr (i == 1) return vr1; else return vr2;
+    };
+    // per-thread slot geometry, computed once
+    int k_goff[3], v_goff[3];   // element offsets inside the K / V^T buffers (token 0 of the tile)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int s = tid + 256 * i;
+        const int r = s / NCH, c = s - r * NCH;
+        k_goff[i] = r * p.ldk + c * 8;
+        const int d = s >> 3, cv = s & 7;
+        v_goff[i] = d * p.vt_ld + cv * 8;
+    }
+    auto load_tile = [&](int t0) __attribute__((always_inline)) {
+        if (t0 + TK <= p.Nk) {   // interior tile: plain loads, no masks
+            static_for<Cfg::K_IT>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const bool in = (i + 1) * 256 <= Cfg::K_SLOTS || tid + 256 * i < Cfg::K_SLOTS;
+                KR(I) = *reinterpret_cast<const uint4*>(Kb + (in ? ((size_t)t0 * p.ldk + k_goff[i]) * 2 : 0));
+            });
+            static_for<Cfg::V_IT>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const bool in = (i + 1) * 256 <= Cfg::V_SLOTS || tid + 256 * i < Cfg::V_SLOTS;
+                VR(I) = *reinterpret_cast<const uint4*>(Vb + (in ? ((size_t)v_goff[i] + t0) * 2 : 0));
+            });
+            return;
+        }
+        static_for<Cfg::K_IT>([&](auto I) __attribute__((always_inline)) {
+            const int s = tid + 256 * decltype(I)::value;
+            const int r = s / NCH, c = s - r * NCH;
+            const int key = t0 + r;
+            const bool ok = s < Cfg::K_SLOTS && key < p.Nk;
+            const uint4 v = *reinterpret_cast<const uint4*>(Kb + (ok ? (size_t)key * p.ldk * 2 + c * 16 : 0));
+            KR(I) = ok ? v : make_uint4(0, 0, 0, 0);
+        });
+        static_for<Cfg::V_IT>([&](auto I) __attribute__((always_inline)) {
+            const int s = tid + 256 * decltype(I)::value;
+            const int d = s >> 3, c = s & 7;
+            const int key = t0 + c * 8;
+            const bool ok = s < Cfg::V_SLOTS && key < p.Nk;
+            uint4 v = *reinterpret_cast<const uint4*>(Vb + (ok ? ((size_t)d * p.vt_ld + key) * 2 : 0));
+            if (!ok) v = make_uint4(0, 0, 0, 0);
+            if (ok && key + 8 > p.Nk) {  // pad keys inside the chunk: 0 * garbage must stay 0
+                uint16_t* w = reinterpret_cast<uint16_t*>(&v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (key + j >= p.Nk) w[j] = 0;
+            }
+            VR(I) = v;
+        });
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        char* sK = smem + buf * (Cfg::K_BYTES + Cfg::V_BYTES);
+        char* sV = sK + Cfg::K_BYTES;
+        static_for<Cfg::K_IT>([&](auto I) __attribute__((always_inline)) {
+            const int s = tid + 256 * decltype(I)::value;
+            const int r = s / NCH, c = s - r * NCH;
+            if (s < Cfg::K_SLOTS) *reinterpret_cast<uint4*>(sK + r * KROW + c * 16) = KR(I);
+        });
+        static_for<Cfg::V_IT>([&](auto I) __attribute__((always_inline)) {
+            const int s = tid + 256 * decltype(I)::value;
+            const int d = s >> 3, c = s & 7;
+            if (s < Cfg::V_SLOTS) *reinterpret_cast<uint4*>(sV + d * VROW + c * 16) = VR(I);
+        });
+    };
+
+    f32x4 o[NTD][2];
+#pragma unroll
+    for (int n = 0; n < NTD; ++n) { o[n][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[n][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float mrow[2] = {-INFINITY, -INFINITY};   // running max of the RAW logits (scale > 0)
+    float lrow[2] = {0.f, 0.f};
+    const float sl2 = p.scale * 1.4426950408889634f;
+
+    load_tile(0);
+    __syncthreads();   // zero fill done before the first tile lands on top of it
+    store_tile(0);
+    __syncthreads();
+
+    const int ntiles = (p.Nk + TK - 1) / TK;
+    for (int t = 0; t < ntiles; ++t) {
+        const int t0 = t * TK;
+        const int buf = t & 1;
+        if (t + 1 < ntiles) load_tile(t0 + TK);
+        const char* sK = smem + buf * (Cfg::K_BYTES + Cfg::V_BYTES);
+        const char* sV = sK + Cfg::K_BYTES;
+
+        f32x4 s[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * KROW + (ks * 4 + fq) * 16);
+                mma16<false>(kf, qf[ks][0], s[kt][0]);
+                mma16<false>(kf, qf[ks][1], s[kt][1]);
+            }
+        }
+        if (t0 + TK > p.Nk) {  // ragged last tile: mask the pad keys
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (t0 + kt * 16 + fq * 4 + j >= p.Nk) { s[kt][0][j] = -INFINITY; s[kt][1][j] = -INFINITY; }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = max3f(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+            mx = max3f(mx, s[0][qt][3], s[1][qt][0]);
+            mx = max3f(mx, s[1][qt][1], s[1][qt][2]);
+            mx = max3f(mx, s[1][qt][3], s[2][qt][0]);
+            mx = max3f(mx, s[2][qt][1], s[2][qt][2]);
+            mx = max3f(mx, s[2][qt][3], s[3][qt][0]);
+            mx = max3f(mx, s[3][qt][1], s[3][qt][2]);
+            mx = max3f(mx, mx, s[3][qt][3]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrow[qt], mx);
+            const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * sl2);
+            mrow[qt] = mnew;
+            const float nm = -mnew * sl2;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][j], sl2, nm));
+                    s[kt][qt][j] = e;
+                    ps += e;
+                }
+            lrow[qt] = fmaf(lrow[qt], alpha, ps);
+#pragma unroll
+            for (int n = 0; n < NTD; ++n) o[n][qt] *= alpha;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            uint4 pf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                pf[qt].x = pack2bf(s[2 * u][qt][0], s[2 * u][qt][1]);
+                pf[qt].y = pack2bf(s[2 * u][qt][2], s[2 * u][qt][3]);
+                pf[qt].z = pack2bf(s[2 * u + 1][qt][0], s[2 * u + 1][qt][1]);
+                pf[qt].w = pack2bf(s[2 * u + 1][qt][2], s[2 * u + 1][qt][3]);
+            }
+#pragma unroll
+            for (int n = 0; n < NTD; ++n) {
+                const char* row = sV + (n * 16 + fr) * VROW;
+                const uint2 lo = *reinterpret_cast<const uint2*>(row + ((2 * u) * 16 + fq * 4) * 2);
+                const uint2 hi = *reinterpret_cast<const uint2*>(row + ((2 * u + 1) * 16 + fq * 4) * 2);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                mma16<false>(vf, pf[0], o[n][0]);
+                mma16<false>(vf, pf[1], o[n][1]);
+            }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);   // buffer buf^1 was last read in tile t-1 (barrier below)
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lrow[qt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q0 + qt * 16 + fr;
+        if (q >= p.Nq) continue;
+#pragma unroll
+        for (int n = 0; n < NTD; ++n) {
+            const int d = n * 16 + fq * 4;
+            if (d >= DH) continue;
+            store4(p.O, (size_t)b * p.o_bs + (size_t)q * p.ldo + (size_t)h * DH + d, DT_BF16, o[n][qt] * inv);
+        }
+    }
+}
+
+template <int DH>
+int launch_attn2(const AttnParams& p, hipStream_t s) {
+    using Cfg = Attn2Cfg<DH>;
+    static bool attr_done = false;
+    auto kfn = attn2_kernel<DH>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Cfg::SMEM) != hipSuccess)
+            return 1;
+        attr_done = true;
+    }
+    dim3 grid((p.Nq + 127) / 128, p.B * p.heads);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), Cfg::SMEM, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 template <bool F32, int DH>
 int launch_dh(const AttnParams& p, hipStream_t s) {
     using Cfg = AttnCfg<F32, DH>;
@@ -258,5 +507,16 @@ int launch_prec(const AttnParams& p, hipStream_t s) {
 
 int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s) {
     if (p.Nq <= 0 || p.Nk <= 0) return 0;
+    if (!f32mode && !p.legacy) {
+        switch (p.dh) {
+            case 8: return launch_attn2<8>(p, s);
+            case 16: return launch_attn2<16>(p, s);
+            case 32: return launch_attn2<32>(p, s);
+            case 40: return launch_attn2<40>(p, s);
+            case 64: return launch_attn2<64>(p, s);
+            case 80: return launch_attn2<80>(p, s);
+            default: break;
+        }
+    }
     return f32mode ? launch_prec<true>(p, s) : launch_prec<false>(p, s);
 }

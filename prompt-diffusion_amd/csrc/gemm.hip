@@ -34,7 +34,10 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row * BKB) + ((
 // F32: fp32 MFMA mode.  CONV: 3x3 gather (else rows of A are contiguous).  AF32: bf16 compute with an
 // fp32 A source (converted while staging; only meaningful when !F32).
 template <bool F32, int BM, int WM, int WN, bool CONV, bool AF32>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(GemmParams p) {
+    // register prefetch depth: two K steps ahead (two named staging sets) unless the fp32->bf16 staging
+    // path already doubles the A registers
+    constexpr int DEPTH = AF32 ? 1 : 2;
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int A_ITERS = BM * 8 / NTHREADS;                   // 16-byte chunks per thread per K step
     constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;  // last one masked when it does not divide
@@ -108,26 +111,38 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(GemmParams p) {
     // Staging registers are NAMED scalars reached through constexpr selectors: hipcc leaves small indexed
     // arrays captured by these lambdas in scratch memory, which serialises every prefetch behind a wait.
     static_assert(A_ITERS <= 4 && B_ITERS <= 5, "staging registers below cover 4 A and 5 B pieces");
-    uint4 ra0, ra1, ra2, ra3, rh0, rh1, rh2, rh3, rb0, rb1, rb2, rb3, rb4;
-    auto RA = [&](auto I) __attribute__((always_inline)) -> uint4& {
+    uint4 ra0, ra1, ra2, ra3, rh0, rh1, rh2, rh3, rb0, rb1, rb2, rb3, rb4;   // set 0
+    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3, sb4;                       // set 1 (DEPTH 2 only)
+    auto RA = [&](auto S, auto I) __attribute__((always_inline)) -> uint4& {
         constexpr int i = decltype(I)::value;
-        if constexpr (i == 0) return ra0; else if constexpr (i == 1) return ra1; else if constexpr (i == 2) return ra2; else return ra3;
+        if constexpr (decltype(S)::value == 0) {
+            if constexpr (i == 0) return ra0; else if constexpr (i == 1) return ra1; else if constexpr (i == 2) return ra2; else return ra3;
+        } else {
+            if constexpr (i == 0) return sa0; else if constexpr (i == 1) return sa1; else if constexpr (i == 2) return sa2; else return sa3;
+        }
     };
-    auto RH = [&](auto I) __attribute__((always_inline)) -> uint4& {  // second 16 B of an fp32 A source (AF32)
+    auto RH = [&](auto I) __attribute__((always_inline)) -> uint4& {  // second 16 B of an fp32 A source (AF32, set 0 only)
         constexpr int i = decltype(I)::value;
         if constexpr (i == 0) return rh0; else if constexpr (i == 1) return rh1; else if constexpr (i == 2) return rh2; else return rh3;
     };
-    auto RB = [&](auto I) __attribute__((always_inline)) -> uint4& {
+    auto RB = [&](auto S, auto I) __attribute__((always_inline)) -> uint4& {
         constexpr int i = decltype(I)::value;
-        if constexpr (i == 0) return rb0; else if constexpr (i == 1) return rb1; else if constexpr (i == 2) return rb2;
-        else if constexpr (i == 3) return rb3; else return rb4;
+        if constexpr (decltype(S)::value == 0) {
+            if constexpr (i == 0) return rb0; else if constexpr (i == 1) return rb1; else if constexpr (i == 2) return rb2;
+            else if constexpr (i == 3) return rb3; else return rb4;
+        } else {
+            if constexpr (i == 0) return sb0; else if constexpr (i == 1) return sb1; else if constexpr (i == 2) return sb2;
+            else if constexpr (i == 3) return sb3; else return sb4;
+        }
     };
+    unsigned rokmask1 = 0;
     unsigned rokmask = 0;
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
     const char* Ab = reinterpret_cast<const char*>(p.A);
 
     // issue every global load of K step kt; nothing here branches per lane
-    auto gload = [&](int kt) __attribute__((always_inline)) {
+    auto gload = [&](auto S, int kt) __attribute__((always_inline)) {
+        unsigned& rmask = decltype(S)::value == 0 ? rokmask : rokmask1;
         const int k0 = kt * BKE + chunk * VEC;
         const bool kok = k0 < p.K;
         int ky = 0, kx = 0, cof = k0;
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(GemmParams p) {
             ky = tap / 3;
             kx = tap - ky * 3;
         }
-        rokmask = 0;
+        rmask = 0;
         static_for<A_ITERS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             bool ok = a_ok[i] && kok;
@@ -151,41 +166,42 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(GemmParams p) {
                 idx = a_base[i] + cof;
             }
             idx = ok ? idx : 0;
-            rokmask |= ok ? (1u << i) : 0u;
+            rmask |= ok ? (1u << i) : 0u;
             const uint4* s = reinterpret_cast<const uint4*>(Ab + idx * AEB);
-            RA(I) = s[0];
+            RA(S, I) = s[0];
             if constexpr (AEB == 4 && !F32) RH(I) = s[1];
         });
         static_for<B_ITERS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            RB(I) = *reinterpret_cast<const uint4*>(w_ptr[i] + (size_t)kt * BKE * EB);
+            RB(S, I) = *reinterpret_cast<const uint4*>(w_ptr[i] + (size_t)kt * BKE * EB);
         });
     };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
+    auto lstore = [&](auto S, int buf) __attribute__((always_inline)) {
+        const unsigned rmask = decltype(S)::value == 0 ? rokmask : rokmask1;
         char* sa = smem + buf * (BM + BN) * BKB;
         char* sb = sa + BM * BKB;
         static_for<A_ITERS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             uint4 v;
             if constexpr (F32) {
-                v = RA(I);
+                v = RA(S, I);
                 if (p.a_silu) {
                     float* f = reinterpret_cast<float*>(&v);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
                 }
             } else if constexpr (AF32) {
-                v = cvt8(RA(I), RH(I), p.a_silu != 0);
+                v = cvt8(RA(S, I), RH(I), p.a_silu != 0);
             } else {
-                v = RA(I);
+                v = RA(S, I);
             }
-            if (!(rokmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
+            if (!(rmask & (1u << i))) v = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(sa + swz(row0 + ROWS_PER_IT * i, chunk)) = v;
         });
         static_for<B_ITERS>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             if (BN % ROWS_PER_IT == 0 || row0 + ROWS_PER_IT * i < BN)
-                *reinterpret_cast<uint4*>(sb + swz(row0 + ROWS_PER_IT * i, chunk)) = RB(I);
+                *reinterpret_cast<uint4*>(sb + swz(row0 + ROWS_PER_IT * i, chunk)) = RB(S, I);
         });
     };
 
@@ -195,17 +211,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(GemmParams p) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (kt0 < kt1) {
-        gload(kt0);
-        lstore(0);
-    }
-    __syncthreads();
-
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) gload(kt + 1);
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const char* sa = smem + buf * (BM + BN) * BKB;
         const char* sb = sa + BM * BKB;
 #pragma unroll
@@ -220,8 +227,43 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) mma<F32>(wf[n], af[m], acc[n][m]);
         }
-        if (more) lstore(buf ^ 1);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    if constexpr (DEPTH == 1) {
+        if (kt0 < kt1) {
+            gload(S0{}, kt0);
+            lstore(S0{}, 0);
+        }
         __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            const bool more = kt + 1 < kt1;
+            if (more) gload(S0{}, kt + 1);
+            compute(buf);
+            if (more) lstore(S0{}, buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // tile kt is computed from LDS buffer (kt-kt0)&1 while tile kt+1 waits in the other register set and
+        // tile kt+2 is being requested: every global load has two K steps of MFMAs to land
+        if (kt0 < kt1) {
+            gload(S0{}, kt0);
+            lstore(S0{}, 0);
+            if (kt0 + 1 < kt1) gload(S1{}, kt0 + 1);
+        }
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            if (kt + 2 < kt1) gload(S0{}, kt + 2);
+            compute(0);
+            if (kt + 1 < kt1) lstore(S1{}, 1);
+            __syncthreads();
+            if (kt + 1 >= kt1) break;
+            if (kt + 3 < kt1) gload(S1{}, kt + 3);
+            compute(1);
+            if (kt + 2 < kt1) lstore(S0{}, 0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds channels n..n+3 (rows of the swapped MFMA) of pixel m

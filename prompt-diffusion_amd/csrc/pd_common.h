@@ -16,8 +16,17 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(uint16_t, b);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    // one v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) instead of two converts + shift + or
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;  // single instruction: hipcc otherwise canonicalises MFMA outputs with extra v_max before fmaxf
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -87,6 +96,7 @@ struct AttnParams {
     int Nq, Nk, heads, dh;
     float scale;
     int B;
+    int legacy;  // 1: use the single-buffered reference kernel (debug)
 };
 
 int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s);

@@ -4,10 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from prompt_diffusion_amd import engine as E, weights as W
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--steps", type=int, default=4); ap.add_argument("--out", default="gpurun_out/shapes.csv"); ap.add_argument("--precision", default="bf16")
+ap.add_argument("--steps", type=int, default=4); ap.add_argument("--out", default="gpurun_out/shapes.csv"); ap.add_argument("--precision", default="bf16"); ap.add_argument("--opt", action="append", default=[])
 a = ap.parse_args()
 cfg = W.SD15; B = a.batch; h = w = a.size // 8; dev = torch.device("cuda", 0)
 e = E.Engine(cfg, precision=a.precision); e.init_random_weights(1)
+for o in a.opt:
+    k, v = o.split('='); e.set_option(k, int(v))
 g = torch.Generator(device=dev).manual_seed(0)
 kw = dict(x_T=torch.randn((B, 4, h, w), generator=g, device=dev), ctx_cond=torch.randn((B, 77, 768), generator=g, device=dev),
           ctx_uncond=torch.randn((B, 77, 768), generator=g, device=dev), pair=torch.rand((B, 6, 8 * h, 8 * w), generator=g, device=dev),
