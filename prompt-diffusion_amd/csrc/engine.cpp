@@ -536,7 +536,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         const int tiles = gemm_tiles(p.M, m.N);
         const int ktiles = m.Kpad / (128 / (int)dt_size(T));
         int splitk = 1;
-        if (!m.geglu && !VT && tiles < 384 && ktiles >= 16 && m.N % 4 == 0) {
+        if (!m.geglu && !VT && tiles < opt_splitk_tiles && ktiles >= 16 && m.N % 4 == 0) {
             splitk = (512 + tiles - 1) / tiles;
             if (splitk > ktiles / 8) splitk = ktiles / 8;
             if (splitk > 8) splitk = 8;
@@ -580,7 +580,7 @@ int pd_engine::conv(const ConvW& c, const Act& in, Act& out, int act, float scal
 int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu) {
     if (arena.dry) return 0;
     const int HW = x.H * x.W;
-    int nchunk = HW / 64;
+    int nchunk = HW / 8;   // enough blocks to fill the chip at the 8x8 / 16x16 levels too
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 64) nchunk = 64;
     while ((size_t)x.B * nchunk * 32 * 2 * sizeof(double) > gn_partial_cap && nchunk > 1) nchunk /= 2;

@@ -178,6 +178,7 @@ struct pd_engine {
     Arena arena;
     Session ses;
     int verbose = 0;
+    int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
     bool opt_bigtile = true;  // 256-row GEMM tiles where the grid still fills the chip
     bool opt_patch = true;  // use the LDS-patch conv3x3 kernel where eligible

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(GemmParams p) {
                     }
                     f32x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = x[j] * gelu_f(g[j]);
+                    for (int j = 0; j < 4; ++j) o[j] = x[j] * (F32 ? gelu_f(g[j]) : gelu_fast(g[j]));
                     store4(p.C, (size_t)gm * p.ldc + on, p.c_dt, o);
                 }
             }

@@ -80,12 +80,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const void* __rest
     }
 }
 
+// y = x * a[c] + b[c] with a = rstd[g] * gamma[c], b = beta[c] - mean[g] * a: each thread owns one 16-byte
+// channel vector (its a/b live in registers) and walks the pixels of the block's slab -- no integer
+// division or per-element group lookup in the loop.
 template <bool XF32, bool YF32>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                                const double* __restrict__ partial,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               int HW, int C, int groups, int nchunk, int nblk_per_sample,
+                                                               int HW, int C, int groups, int nchunk, int napply,
                                                                float eps, int do_silu) {
+    constexpr int VEC = XF32 ? 4 : 8;  // elements per 16-byte input vector
     __shared__ float s_mean[64], s_rstd[64];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
@@ -105,25 +109,62 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
     }
     __syncthreads();
     const int cpg = C / groups;
-    const int nvec4 = C / 4;
-    const long long total = (long long)HW * nvec4;
-    const long long per = (total + nblk_per_sample - 1) / nblk_per_sample;
-    const long long i0 = blockIdx.x * per, i1 = min(total, i0 + per);
-    for (long long i = i0 + tid; i < i1; i += GN_THREADS) {
-        const int v = (int)(i % nvec4);
-        const size_t idx = (size_t)b * HW * C + (size_t)i * 4;
-        f32x4 t = load4(x, idx, XF32 ? DT_F32 : DT_BF16);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + v * 4);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(beta + v * 4);
-        f32x4 o;
+    const int nvec = C / VEC;
+    const int lanes = min(nvec, GN_THREADS);
+    const int rows_par = GN_THREADS / lanes;
+    const int pr = tid / lanes, vc = tid - pr * lanes;
+    if (pr >= rows_par) return;
+    const int ppc = (HW + napply - 1) / napply;
+    const int p0 = blockIdx.x * ppc, p1 = min(HW, p0 + ppc);
+    const char* xb = reinterpret_cast<const char*>(x) + (size_t)b * HW * C * (XF32 ? 4 : 2);
+    char* yb = reinterpret_cast<char*>(y) + (size_t)b * HW * C * (YF32 ? 4 : 2);
+    for (int v = vc; v < nvec; v += lanes) {
+        float ka[VEC], kb[VEC];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int grp = (v * 4 + j) / cpg;
-            float r = (t[j] - s_mean[grp]) * s_rstd[grp] * g[j] + be[j];
-            if (do_silu) r = silu_f(r);
-            o[j] = r;
+        for (int j = 0; j < VEC; ++j) {
+            const int c = v * VEC + j;
+            const int g = c / cpg;
+            ka[j] = s_rstd[g] * gamma[c];
+            kb[j] = beta[c] - s_mean[g] * ka[j];
         }
-        store4(y, idx, YF32 ? DT_F32 : DT_BF16, o);
+        for (int p = p0 + pr; p < p1; p += rows_par) {
+            const size_t e = (size_t)p * C + (size_t)v * VEC;   // element index inside the sample
+            const uint4 raw = *reinterpret_cast<const uint4*>(xb + e * (XF32 ? 4 : 2));
+            float f[VEC];
+            if constexpr (XF32) {
+                const float* t = reinterpret_cast<const float*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = t[j];
+            } else {
+                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[2 * j] = __uint_as_float(w[j] << 16);
+                    f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float r = fmaf(f[j], ka[j], kb[j]);
+                f[j] = do_silu ? silu_f(r) : r;
+            }
+            if constexpr (YF32) {
+                float* o = reinterpret_cast<float*>(yb) + e;
+#pragma unroll
+                for (int h = 0; h < VEC / 4; ++h) *reinterpret_cast<f32x4*>(o + 4 * h) = f32x4{f[4 * h], f[4 * h + 1], f[4 * h + 2], f[4 * h + 3]};
+            } else {
+                uint16_t* o = reinterpret_cast<uint16_t*>(yb) + e;
+                if constexpr (VEC == 8) {
+                    uint4 u;
+                    u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
+                    *reinterpret_cast<uint4*>(o) = u;
+                } else {
+                    uint2 u;
+                    u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]);
+                    *reinterpret_cast<uint2*>(o) = u;
+                }
+            }
+        }
     }
 }
 
@@ -191,14 +232,14 @@ int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int
 
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
                     const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s) {
-    long long total = (long long)HW * (C / 4);
-    int nblk = (int)((total + GN_THREADS * 8 - 1) / (GN_THREADS * 8));
-    if (nblk < 1) nblk = 1;
-    if (nblk > 512) nblk = 512;
-    dim3 grid(nblk, B);
+    // pixel slabs per sample: aim at >= 2048 blocks, at least 4 pixels per thread row
+    int napply = (2048 + B - 1) / B;
+    if (napply > HW / 4) napply = HW / 4;
+    if (napply < 1) napply = 1;
+    dim3 grid(napply, B);
 #define GN_AP(XF, YF)                                                                                                 \
     hipLaunchKernelGGL((gn_apply_kernel<XF, YF>), grid, dim3(GN_THREADS), 0, s, x, y, partial, gamma, beta, HW, C, \
-                       groups, nchunk, nblk, eps, silu)
+                       groups, nchunk, napply, eps, silu)
     if (x_dt == DT_F32 && y_dt == DT_F32) GN_AP(true, true);
     else if (x_dt == DT_F32) GN_AP(true, false);
     else if (y_dt == DT_F32) GN_AP(false, true);

@@ -568,6 +568,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!e || !key) { pd_set_error("null argument"); return 1; }
     if (!strcmp(key, "verbose")) { e->verbose = (int)value; return 0; }
     if (!strcmp(key, "conv_patch")) { e->opt_patch = value != 0; return 0; }
+    if (!strcmp(key, "splitk_tiles")) { e->opt_splitk_tiles = (int)value; return 0; }
     if (!strcmp(key, "attn_legacy")) { e->opt_attn_legacy = value != 0; return 0; }
     if (!strcmp(key, "big_tile")) { e->opt_bigtile = value != 0; return 0; }
     if (!strcmp(key, "profile")) {
