@@ -1,0 +1,114 @@
+"""The reference-shaped host surfaces on the GPU: DDIMSampler.sample ((L), cldm/ddim_hacked.py:55) against the
+reference's own trajectory, and PromptDiffusionPipeline.__call__ ((D), pipeline_prompt_diffusion.py:890) against
+an oracle replay of the (D)-specific loop logic (guess mode, controlnet_keep window, [0,1] images)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pd_oracle as O
+from prompt_diffusion_amd import engine as E
+from prompt_diffusion_amd import weights as W
+from prompt_diffusion_amd.ddim import ControlLDM, DDIMSampler
+from prompt_diffusion_amd.pipeline import PromptDiffusionPipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = E.Engine(W.TINY, precision="f32")
+    e.load_state_dict(W.synth_state_dict(W.TINY))
+    yield e
+    e.close()
+
+
+def test_ddim_sampler_surface_matches_reference_run(golden_dir, eng):
+    g = np.load(os.path.join(golden_dir, "net_tiny_b2_16x16_s5.npz"))
+    B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
+    inp = W.synth_inputs(W.TINY, B, h, w)
+    model = ControlLDM(eng)
+    sampler = DDIMSampler(model)
+    cond = {"c_crossattn": [inp["ctx_cond"]], "example_pair": [inp["pair"]], "query": [inp["query"]]}
+    uc = {"c_crossattn": [inp["ctx_uncond"]], "example_pair": [inp["pair"]], "query": [inp["query"]]}
+    calls, preds = [], []
+    samples, inter = sampler.sample(S, B, (4, h, w), cond, eta=0.0, x_T=inp["x_T"], unconditional_guidance_scale=float(g["cfg_scale"]),
+                                    unconditional_conditioning=uc, log_every_t=1, verbose=False,
+                                    callback=calls.append, img_callback=lambda p, i: preds.append((i, p)))
+    assert calls == list(range(S)) and [i for i, _ in preds] == list(range(S))
+    assert len(inter["x_inter"]) == S + 1 and len(inter["pred_x0"]) == S + 1
+    for i in range(S + 1):
+        assert relerr(inter["x_inter"][i], g["x_inter"][i]) < 2e-4
+        assert relerr(inter["pred_x0"][i], g["pred_x0"][i]) < 2e-4
+    assert relerr(samples, g["samples"]) < 2e-4
+    # default log_every_t=100: x_T, the first step (index == total-1) and the last (index 0), ddim_hacked.py:174
+    _, inter2 = sampler.sample(S, B, (4, h, w), cond, eta=0.0, x_T=inp["x_T"], unconditional_guidance_scale=float(g["cfg_scale"]),
+                               unconditional_conditioning=uc, verbose=False)
+    assert len(inter2["x_inter"]) == 3
+    # apply_model boundary
+    t = np.full((B,), int(g["first_step"]), np.int64)
+    eps = model.apply_model(inp["x_T"], t, cond)
+    assert relerr(eps, g["eps"][B:]) < 2e-4
+
+
+def _oracle_pipeline(cfg, sd, lay, x_T, pe, ne, pair, query, S, gs, scale, guess, g_start, g_end):
+    """Replay of pipeline_prompt_diffusion.py:1196-1273 with the oracle's networks and a DDIM step."""
+    sched = O.make_schedule(S)
+    n = len(sched["ddim_timesteps"])
+    keep = [1.0 - float(i / n < g_start or (i + 1) / n > g_end) for i in range(n)]
+    B = x_T.shape[0]
+    x = x_T
+    for i, step in enumerate(np.flip(sched["ddim_timesteps"])):
+        index = n - i - 1
+        base = np.logspace(-1, 0, 13).astype(np.float32) if guess else np.ones(13, np.float32)
+        scales = base * np.float32(scale) * np.float32(keep[i])
+        x_in = np.concatenate([x, x]); t_in = np.full((2 * B,), int(step), np.int64)
+        ctx = np.concatenate([ne, pe]); pr = np.concatenate([pair, pair]); qr = np.concatenate([query, query])
+        if guess:   # ControlNet on the conditional half only, zeros for the unconditional half (:1220-1224,:1248-1253)
+            ctl = O.controlnet_forward(sd, cfg, lay, x, t_in[:B], pair, query, pe)
+            ctl = [np.concatenate([np.zeros_like(c), c]) * s for c, s in zip(ctl, scales)]
+        else:
+            ctl = O.controlnet_forward(sd, cfg, lay, x_in, t_in, pr, qr, ctx)
+            ctl = [c * s for c, s in zip(ctl, scales)]
+        eps = O.controlled_unet_forward(sd, cfg, lay, x_in, t_in, ctx, ctl)
+        e = eps[:B] + np.float32(gs) * (eps[B:] - eps[:B])
+        a_t, a_prev = sched["ddim_alphas"][index], sched["ddim_alphas_prev"][index]
+        pred = (x - sched["ddim_sqrt_one_minus_alphas"][index] * e) / np.sqrt(a_t)
+        x = (np.sqrt(a_prev) * pred + np.sqrt(np.float32(1.0) - a_prev) * e).astype(np.float32)
+    return x
+
+
+@pytest.mark.parametrize("guess,g_end", [(False, 1.0), (True, 0.6)])
+def test_pipeline_call_against_oracle(eng, guess, g_end):
+    cfg = W.TINY
+    B, hw, S = 2, 64, 4
+    inp = W.synth_inputs(cfg, B, hw // 8, hw // 8, seed=11, unit_range=True)
+    sd = W.synth_state_dict(cfg)
+    lay = O.make_layouts(cfg, W)
+    pipe = PromptDiffusionPipeline(eng)
+    a, b = inp["pair"][:, :3], inp["pair"][:, 3:]
+    seen = []
+    out = pipe(prompt_embeds=inp["ctx_cond"], negative_prompt_embeds=inp["ctx_uncond"],
+               image=inp["query"].transpose(0, 2, 3, 1), image_pair=[a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1)],
+               num_inference_steps=S, guidance_scale=5.0, latents=inp["x_T"], output_type="latent",
+               controlnet_conditioning_scale=0.8, guess_mode=guess, control_guidance_end=g_end,
+               callback_on_step_end=(lambda p, i, t, kw: seen.append((i, int(t))) or {}) if guess else None)
+    ref = _oracle_pipeline(cfg, sd, lay, inp["x_T"], inp["ctx_cond"], inp["ctx_uncond"], inp["pair"], inp["query"], S, 5.0, 0.8,
+                           guess, 0.0, g_end)
+    assert out.nsfw_content_detected is None
+    assert relerr(out.images, ref) < 3e-4
+    if guess:
+        assert [i for i, _ in seen] == list(range(S)) and seen[0][1] == 751
+    tup = pipe(prompt_embeds=inp["ctx_cond"], negative_prompt_embeds=inp["ctx_uncond"], image=inp["query"].transpose(0, 2, 3, 1),
+               image_pair=[a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1)], num_inference_steps=S, guidance_scale=5.0,
+               latents=inp["x_T"], output_type="latent", controlnet_conditioning_scale=0.8, guess_mode=guess,
+               control_guidance_end=g_end, return_dict=False)
+    assert isinstance(tup, tuple) and tup[1] is None
+    np.testing.assert_allclose(np.asarray(tup[0]), np.asarray(out.images), rtol=0, atol=0)
+    with pytest.raises(ValueError, match="vae_decode"):
+        pipe(prompt_embeds=inp["ctx_cond"], negative_prompt_embeds=inp["ctx_uncond"], image=inp["query"].transpose(0, 2, 3, 1),
+             image_pair=[a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1)], num_inference_steps=S, latents=inp["x_T"])
