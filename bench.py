@@ -143,20 +143,27 @@ def main():
             eng.ddim_sample(**kw)
             peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
             classes = {}
-            for name, k in (("conv3x3_igemm", 0), ("linear_igemm", 1), ("attention", 2)):
+            for name, k in (("igemm_kernel[conv3x3]", 0), ("igemm_kernel[linear/conv1x1]", 1), ("conv3x3_patch_kernel", 3),
+                            ("attn_kernel", 2)):
                 ms, n, fl = eng.profile_read(k)
                 classes[name] = dict(ms=ms, launches=n, avg_us=1e3 * ms / max(n, 1), tflops=fl / max(ms, 1e-9) / 1e9)
             eng.set_option("profile", 0)
-            ms0, n0, fl0 = eng.profile_read(-1)
-            ms_g = classes["conv3x3_igemm"]["ms"] + classes["linear_igemm"]["ms"]
-            n_g = classes["conv3x3_igemm"]["launches"] + classes["linear_igemm"]["launches"]
-            fl_g = (classes["conv3x3_igemm"]["tflops"] * classes["conv3x3_igemm"]["ms"] +
-                    classes["linear_igemm"]["tflops"] * classes["linear_igemm"]["ms"])
+            # dominant kernel by device time: igemm_kernel (every instantiation: linear / conv1x1 / generic conv3x3).
+            # Each bracket is ONE launch of that kernel (split-K finalize excluded), so avg_launch_us is comparable
+            # with rocprofv3's call-weighted average over the igemm_kernel<...> rows (profiles/).
+            ms_g = classes["igemm_kernel[conv3x3]"]["ms"] + classes["igemm_kernel[linear/conv1x1]"]["ms"]
+            n_g = classes["igemm_kernel[conv3x3]"]["launches"] + classes["igemm_kernel[linear/conv1x1]"]["launches"]
+            fl_g = sum(classes[k]["tflops"] * classes[k]["ms"] for k in ("igemm_kernel[conv3x3]", "igemm_kernel[linear/conv1x1]"))
             achieved = fl_g / max(ms_g, 1e-9)
-            result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3 + conv1x1/linear implicit GEMM)",
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("igemm_kernel_hbm_bytes_per_launch")
+            result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv / linear, all instantiations)",
                                   "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                                  "traffic": None, "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,
-                                  "device_ms_per_pass": ms_g, "by_class": classes}
+                                  "traffic": traffic, "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,
+                                  "flop_per_launch": 1e9 * fl_g / max(n_g, 1), "device_ms_per_pass": ms_g, "by_kernel": classes}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(result))

@@ -155,7 +155,8 @@ void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches o
 int pd_set_option(pd_engine* e, const char* key, int64_t value); /* "use_graph", "verbose" ... */
 int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches_per_step" */
 /* Per-launch timing: while option "profile" is 1 the engine brackets every contraction launch with HIP
- * events on its stream.  klass 0 = conv3x3 implicit GEMM, 1 = conv1x1/linear GEMM, 2 = attention, -1 = all.
+ * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel on a conv1x1/linear,
+ * 2 = attention, 3 = conv3x3_patch_kernel, -1 = all.  One bracket = one launch (split-K finalize excluded).
  * Returns summed device time, launch count and algorithmic FLOPs (2*M*N*K, logical channel counts). */
 int pd_profile_read(pd_engine* e, int32_t klass, double* total_ms, int64_t* n_launches, double* flops);
 int pd_profile_dump(pd_engine* e, const char* csv_path); /* one row per profiled launch */

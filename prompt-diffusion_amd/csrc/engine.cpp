@@ -564,11 +564,17 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         prof_begin(rec, m.taps == 9 ? 0 : 1, 2.0 * (double)p.M * n_log * (double)m.taps * (double)m.cin);
         rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.taps * 10 + p.stride + (p.ups ? 5 : 0);
     }
-    if (use_patch ? launch_conv_patch(p, f32, stream) : launch_gemm(p, f32, stream)) {
+    hipEvent_t mid = nullptr;
+    if (profiling && !use_patch) { mid = next_event(); rec.klass = m.taps == 9 ? 0 : 1; }
+    if (profiling && use_patch) rec.klass = 3;
+    if (use_patch ? launch_conv_patch(p, f32, stream) : launch_gemm(p, f32, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;
     }
-    if (profiling) prof_end(rec);
+    if (profiling) {
+        if (mid) { rec.b = mid; prof.push_back(rec); }   // bracket = the contraction kernel only (no split-K finalize)
+        else prof_end(rec);
+    }
     return 0;
 }
 

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
 }
 
 template <bool F32, int BM, int WM, int WN, bool CONV, bool AF32>
-int launch_one(const GemmParams& p, hipStream_t s) {
+int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB;
     static bool attr_done = false;
@@ -349,6 +349,7 @@ int launch_one(const GemmParams& p, hipStream_t s) {
     dim3 grid(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, s, p);
     if (hipGetLastError() != hipSuccess) return 1;
+    if (mid) (void)hipEventRecord(mid, s);   // profiling: end of the contraction kernel proper
     if (p.splitk > 1) {
         long long total = (long long)p.M * (p.N / 4);
         int nb = (int)((total + 255) / 256);
@@ -363,7 +364,7 @@ int launch_one(const GemmParams& p, hipStream_t s) {
 
 int gemm_tiles(int M, int N) { return ((M + 127) / 128) * ((N + BN - 1) / BN); }
 
-int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s) {
+int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid) {
     if (p.M <= 0 || p.N <= 0) return 0;
     const bool conv = p.taps != 1;
     const bool af32 = p.a_dt == DT_F32;
@@ -372,15 +373,15 @@ int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s) {
     const bool big = p.big_tile && p.splitk == 1;
     if (p.act == 2) {
         if (conv || (!f32mode && af32)) return 1;
-        if (big) return f32mode ? launch_one<true, 256, 8, 1, false, false>(p, s) : launch_one<false, 256, 8, 1, false, false>(p, s);
-        return f32mode ? launch_one<true, 128, 4, 1, false, false>(p, s) : launch_one<false, 128, 4, 1, false, false>(p, s);
+        if (big) return f32mode ? launch_one<true, 256, 8, 1, false, false>(p, s, mid) : launch_one<false, 256, 8, 1, false, false>(p, s, mid);
+        return f32mode ? launch_one<true, 128, 4, 1, false, false>(p, s, mid) : launch_one<false, 128, 4, 1, false, false>(p, s, mid);
     }
     if (big) {
-        if (f32mode) return conv ? launch_one<true, 256, 4, 2, true, false>(p, s) : launch_one<true, 256, 4, 2, false, false>(p, s);
-        if (conv) return af32 ? launch_one<false, 256, 4, 2, true, true>(p, s) : launch_one<false, 256, 4, 2, true, false>(p, s);
-        return af32 ? launch_one<false, 256, 4, 2, false, true>(p, s) : launch_one<false, 256, 4, 2, false, false>(p, s);
+        if (f32mode) return conv ? launch_one<true, 256, 4, 2, true, false>(p, s, mid) : launch_one<true, 256, 4, 2, false, false>(p, s, mid);
+        if (conv) return af32 ? launch_one<false, 256, 4, 2, true, true>(p, s, mid) : launch_one<false, 256, 4, 2, true, false>(p, s, mid);
+        return af32 ? launch_one<false, 256, 4, 2, false, true>(p, s, mid) : launch_one<false, 256, 4, 2, false, false>(p, s, mid);
     }
-    if (f32mode) return conv ? launch_one<true, 128, 2, 2, true, false>(p, s) : launch_one<true, 128, 2, 2, false, false>(p, s);
-    if (conv) return af32 ? launch_one<false, 128, 2, 2, true, true>(p, s) : launch_one<false, 128, 2, 2, true, false>(p, s);
-    return af32 ? launch_one<false, 128, 2, 2, false, true>(p, s) : launch_one<false, 128, 2, 2, false, false>(p, s);
+    if (f32mode) return conv ? launch_one<true, 128, 2, 2, true, false>(p, s, mid) : launch_one<true, 128, 2, 2, false, false>(p, s, mid);
+    if (conv) return af32 ? launch_one<false, 128, 2, 2, true, true>(p, s, mid) : launch_one<false, 128, 2, 2, true, false>(p, s, mid);
+    return af32 ? launch_one<false, 128, 2, 2, false, true>(p, s, mid) : launch_one<false, 128, 2, 2, false, false>(p, s, mid);
 }

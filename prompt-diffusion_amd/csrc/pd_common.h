@@ -112,7 +112,7 @@ struct AttnParams {
     int legacy;  // 1: use the single-buffered reference kernel (debug)
 };
 
-int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s);
+int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid = nullptr);
 int gemm_tiles(int M, int N);
 int conv_patch_tiles(const GemmParams& p, bool f32mode);  // 0: shape not eligible for the LDS-patch conv kernel
 int launch_conv_patch(const GemmParams& p, bool f32mode, hipStream_t s);

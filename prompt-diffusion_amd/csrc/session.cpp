@@ -591,8 +591,8 @@ int64_t pd_get_stat(pd_engine* e, const char* key) {
     return -1;
 }
 
-// Per-launch HIP-event timing collected while option "profile" is on.  klass: 0 conv3x3 implicit GEMM,
-// 1 conv1x1 / linear GEMM, 2 attention, -1 all.
+// Per-launch HIP-event timing collected while option "profile" is on.  klass: 0 igemm conv3x3,
+// 1 igemm conv1x1 / linear, 2 attention, 3 conv3x3 LDS-patch kernel, -1 all.
 int pd_profile_read(pd_engine* e, int32_t klass, double* total_ms, int64_t* n_launches, double* flops) {
     if (!e) { pd_set_error("null engine"); return 1; }
     HIP_OK(hipStreamSynchronize(e->stream));
