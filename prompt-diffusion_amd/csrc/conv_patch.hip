@@ -6,8 +6,8 @@
 // channels.  Per 128-byte channel chunk it stages the (16+2)x(16+2) input patch in LDS ONCE and runs all
 // 9 taps against it, streaming only the [160 x 128 B] weight tile per tap (always L2-resident: every block
 // walks the same weights).  ~3x fewer bytes fetched per FLOP; the patch of chunk c+1 is requested at
-// taps 0/3 of chunk c (two halves through the same registers) and lands in LDS at taps 3/6, so its
-// HBM latency hides under 3 taps of MFMAs; the next tap's weight tile is requested at the top of each tap.
+// piece by piece during taps 0-4 of chunk c and lands in LDS at taps 2-7 (one 16-byte piece per thread per tap),
+// so its HBM latency hides under >= 2 taps of MFMAs; the next tap's weight tile is requested at the top of each tap.
 //
 // 512 threads = 8 waves as 4 (patch rows) x 2 (80 channels); a wave owns 4 patch rows x 80 channels =
 // 4 x 5 MFMA tiles of 16x16, i.e. 40 v_mfma_f32_16x16x32_bf16 per tap and chunk.  An MFMA tile's 16
@@ -42,7 +42,7 @@ struct PatchGeom {
     static constexpr int SMEM = 2 * P_BYTES + 2 * W_TILE;
 };
 
-template <bool F32, int UPS>
+template <bool F32, int UPS, bool GN>
 __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     using G = PatchGeom<UPS>;
     constexpr int EB = F32 ? 4 : 2;
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sP = smem;                    // [2][PROWS][128]
     char* sW = smem + 2 * G::P_BYTES;   // [2][160][128]
+    float* sCoef = reinterpret_cast<float*>(smem + G::SMEM);  // GN: [Cin][2] coefficients of this block's sample
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -83,9 +84,10 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         off = ok ? (unsigned)((((size_t)(sample * p.Hin + gy) * p.Win + gx) * p.lda + ch * VEC) * EB) : 0u;
         lds = s < G::P_SLOTS ? swzp(prow, ch) : -1;
     };
-    unsigned p_off[2 * G::P_HALF];
+    static_assert(G::P_ITERS <= 6, "piece schedule covers 6 pieces");
+    unsigned p_off[G::P_ITERS];
 #pragma unroll
-    for (int j = 0; j < 2 * G::P_HALF; ++j) {
+    for (int j = 0; j < G::P_ITERS; ++j) {
         int lds; bool ok;
         patch_slot(j, lds, ok, p_off[j]);
     }
@@ -106,27 +108,62 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     const int U = nchunks * 9;  // (chunk, tap) units; weights for unit u start at element (u%9)*Cin + (u/9)*BKE
 
     // staging registers as named scalars (hipcc leaves small indexed arrays captured by these lambdas in scratch)
-    static_assert(G::P_HALF <= 3 && W_ITERS == 3, "staging code below is written for <= 3 pieces");
+    static_assert(W_ITERS == 3, "weight staging below is written for 3 pieces");
     uint4 pr0, pr1, pr2, wr0, wr1, wr2;
 
-    // the patch is staged in two halves through the same registers
-    auto load_patch = [&](int c, int half) __attribute__((always_inline)) {
-        const char* base = Ab + (size_t)c * BKE * EB;
-        pr0 = *reinterpret_cast<const uint4*>(base + (half ? p_off[G::P_HALF + 0] : p_off[0]));
-        if constexpr (G::P_HALF > 1) pr1 = *reinterpret_cast<const uint4*>(base + (half ? p_off[G::P_HALF + 1] : p_off[1]));
-        if constexpr (G::P_HALF > 2) pr2 = *reinterpret_cast<const uint4*>(base + (half ? p_off[G::P_HALF + 2] : p_off[2]));
+    // The patch of the next chunk is staged piece by piece through three registers: piece j is requested at tap
+    // (j < 3 ? 0 : j - 1) and written to LDS at tap j + 2, so at most one piece is converted/stored per tap and every
+    // request has >= 2 taps of MFMAs to land.
+    auto PR = [&](auto J) __attribute__((always_inline)) -> uint4& {
+        constexpr int r = decltype(J)::value % 3;
+        if constexpr (r == 0) return pr0; else if constexpr (r == 1) return pr1; else return pr2;
     };
-    auto store_piece = [&](char* d, int j, const uint4& r) __attribute__((always_inline)) {
+    auto load_piece = [&](auto J, int c) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < G::P_ITERS) PR(J) = *reinterpret_cast<const uint4*>(Ab + (size_t)c * BKE * EB + p_off[j]);
+    };
+    // GroupNorm(+SiLU) fused into the staging: y = silu(x * a[c] + b[c]); pad positions stay 0 (the reference
+    // pads the normalised tensor).  A thread's 16-byte piece always covers channels chunk*BKE + (tid&7)*VEC ..
+    auto store_piece = [&](char* d, int j, const uint4& r, int c) __attribute__((always_inline)) {
         int lds; bool ok; unsigned off;
         patch_slot(j, lds, ok, off);
-        const uint4 v = ok ? r : make_uint4(0, 0, 0, 0);
+        uint4 v = r;
+        if constexpr (GN) {
+            const float* cf = sCoef + (size_t)(c * BKE + (tid & 7) * VEC) * 2;
+            float f[VEC];
+            if constexpr (F32) {
+                const float* t = reinterpret_cast<const float*>(&r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = t[e];
+            } else {
+                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[2 * e] = __uint_as_float(w[e] << 16);
+                    f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) {
+                const f32x4 ab = *reinterpret_cast<const f32x4*>(cf + 2 * e);   // a[e], b[e], a[e+1], b[e+1]
+                float y0 = fmaf(f[e], ab[0], ab[1]), y1 = fmaf(f[e + 1], ab[2], ab[3]);
+                if (p.gn_silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
+                f[e] = y0; f[e + 1] = y1;
+            }
+            if constexpr (F32) {
+                float* t = reinterpret_cast<float*>(&v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = f[e];
+            } else {
+                v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+            }
+        }
+        if (!ok) v = make_uint4(0, 0, 0, 0);
         if (lds >= 0) *reinterpret_cast<uint4*>(d + lds) = v;
     };
-    auto store_patch = [&](int buf, int half) __attribute__((always_inline)) {
-        char* d = sP + buf * G::P_BYTES;
-        store_piece(d, half * G::P_HALF + 0, pr0);
-        if constexpr (G::P_HALF > 1) store_piece(d, half * G::P_HALF + 1, pr1);
-        if constexpr (G::P_HALF > 2) store_piece(d, half * G::P_HALF + 2, pr2);
+    auto store_one = [&](auto J, int buf, int c) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < G::P_ITERS) store_piece(sP + buf * G::P_BYTES, j, PR(J), c);
     };
     auto load_w = [&](int c, int tap) __attribute__((always_inline)) {
         const char* base = Wb + ((size_t)tap * p.Cin + (size_t)c * BKE) * EB;
@@ -148,12 +185,19 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: patch 0, weight tile of unit 0 in LDS; unit 1's weights in flight
-    load_patch(0, 0);
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    load_piece(I0{}, 0); load_piece(I1{}, 0); load_piece(I2{}, 0);
     load_w(0, 0);
-    store_patch(0, 0);
-    load_patch(0, 1);
+    if constexpr (GN) {
+        const float* src = p.gn_coef + (size_t)sample * p.Cin * 2;
+        for (int i = tid; i < p.Cin * 2; i += NT) sCoef[i] = src[i];
+        __syncthreads();
+    }
+    store_one(I0{}, 0, 0); store_one(I1{}, 0, 0); store_one(I2{}, 0, 0);
+    load_piece(I3{}, 0); load_piece(I4{}, 0); load_piece(I5{}, 0);
     store_w(0);
-    store_patch(0, 1);
+    store_one(I3{}, 0, 0); store_one(I4{}, 0, 0); store_one(I5{}, 0, 0);
     __syncthreads();
 
     // one (chunk, tap) unit.  Weight tile of unit u sits in LDS buffer u&1; the tile of unit u+1 is requested
@@ -163,7 +207,8 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         constexpr int ky = tap / 3, kx = tap % 3;
         const int u = c * 9 + tap;
         const int par = u & 1;
-        if (tap == 0 && c + 1 < nchunks) load_patch(c + 1, 0);
+        const bool nextc = c + 1 < nchunks;
+        if (tap == 0 && nextc) { load_piece(I0{}, c + 1); load_piece(I1{}, c + 1); load_piece(I2{}, c + 1); }
         if (u + 1 < U) {
             const int c2 = tap + 1 >= 9 ? c + 1 : c;
             load_w(c2, u + 1 - c2 * 9);
@@ -194,8 +239,15 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         }
         if (u + 1 < U) store_w(par ^ 1);
         // next chunk's patch (two halves through the same registers) -> the other patch buffer, last read in chunk c-1
-        if (tap == 3 && c + 1 < nchunks) { store_patch((c + 1) & 1, 0); load_patch(c + 1, 1); }
-        if (tap == 6 && c + 1 < nchunks) store_patch((c + 1) & 1, 1);
+        if (nextc) {
+            const int nb = (c + 1) & 1;
+            if constexpr (tap == 2) { store_one(I0{}, nb, c + 1); load_piece(I3{}, c + 1); }
+            if constexpr (tap == 3) { store_one(I1{}, nb, c + 1); load_piece(I4{}, c + 1); }
+            if constexpr (tap == 4) { store_one(I2{}, nb, c + 1); load_piece(I5{}, c + 1); }
+            if constexpr (tap == 5) store_one(I3{}, nb, c + 1);
+            if constexpr (tap == 6) store_one(I4{}, nb, c + 1);
+            if constexpr (tap == 7) store_one(I5{}, nb, c + 1);
+        }
         __syncthreads();
     };
     for (int c = 0; c < nchunks; ++c) {
@@ -225,19 +277,23 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     }
 }
 
-template <bool F32, int UPS>
+constexpr int COEF_BYTES_MAX = 24 * 1024;   // [Cin <= 3072][2] floats behind the staging buffers
+
+template <bool F32, int UPS, bool GN>
 int launch_patch(const GemmParams& p, hipStream_t s) {
     using G = PatchGeom<UPS>;
     static bool attr_done = false;
-    auto kfn = conv3x3_patch_kernel<F32, UPS>;
+    auto kfn = conv3x3_patch_kernel<F32, UPS, GN>;
+    const int smem = G::SMEM + (GN ? COEF_BYTES_MAX : 0);
+    if (GN && p.Cin * 8 > COEF_BYTES_MAX) return 1;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
             hipSuccess)
             return 1;
         attr_done = true;
     }
     const int mtiles = (p.M / (p.Hout * p.Wout)) * (p.Hout / TP) * (p.Wout / TP), ntiles = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kfn, dim3(mtiles * ntiles), dim3(NT), G::SMEM, s, p);
+    hipLaunchKernelGGL(kfn, dim3(mtiles * ntiles), dim3(NT), smem, s, p);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -249,11 +305,16 @@ int conv_patch_tiles(const GemmParams& p, bool f32mode) {
     if (p.taps != 9 || p.stride != 1 || p.splitk > 1) return 0;
     if (p.Hout % TP || p.Wout % TP || p.Cin % bke || p.K != 9 * p.Cin || p.act == 2 || p.vt_begin < p.N) return 0;
     if (p.a_dt != (f32mode ? DT_F32 : DT_BF16) || p.a_silu) return 0;
+    if (p.Cin * 8 > 24 * 1024) return 0;
     if ((p.Hin << p.ups) != p.Hout || (p.Win << p.ups) != p.Wout) return 0;
     return (p.M / (p.Hout * p.Wout)) * (p.Hout / TP) * (p.Wout / TP) * ((p.N + BN - 1) / BN);
 }
 
 int launch_conv_patch(const GemmParams& p, bool f32mode, hipStream_t s) {
-    if (p.ups) return f32mode ? launch_patch<true, 1>(p, s) : launch_patch<false, 1>(p, s);
-    return f32mode ? launch_patch<true, 0>(p, s) : launch_patch<false, 0>(p, s);
+    if (p.gn_coef) {
+        if (p.ups) return 1;   // GroupNorm never feeds an upsampling conv in this network
+        return f32mode ? launch_patch<true, 0, true>(p, s) : launch_patch<false, 0, true>(p, s);
+    }
+    if (p.ups) return f32mode ? launch_patch<true, 1, false>(p, s) : launch_patch<false, 1, false>(p, s);
+    return f32mode ? launch_patch<true, 0, false>(p, s) : launch_patch<false, 0, false>(p, s);
 }

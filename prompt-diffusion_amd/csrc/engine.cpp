@@ -501,7 +501,8 @@ Act pd_engine::new_act(int B, int H, int W, int C, int dt) {
 }
 
 int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups, int act, float scale, const Act* R,
-                    const float* rowvec, int rowvec_stride, bool a_silu, void* VT, int vt_begin, int vt_ld, int ldc_override) {
+                    const float* rowvec, int rowvec_stride, bool a_silu, void* VT, int vt_begin, int vt_ld, int ldc_override,
+                    const float* gn_coef, bool gn_silu) {
     if (in.C != m.cin_pad) {
         pd_set_error("gemm: input has %d channels, layer expects %d", in.C, m.cin_pad);
         return 1;
@@ -528,8 +529,14 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.Nout = m.Nout;
     p.splitk = 1;
     p.slab = nullptr;
+    p.gn_coef = gn_coef;
+    p.gn_silu = gn_silu ? 1 : 0;
     // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
     const bool use_patch = opt_patch && conv_patch_tiles(p, f32) >= 192;
+    if (gn_coef && !use_patch) {
+        pd_set_error("internal: fused GroupNorm requested for a conv that is not patch-eligible");
+        return 1;
+    }
     // otherwise split K when the tile grid cannot fill the chip (8x8 / 16x16 levels, time-embedding GEMMs)
     if (!use_patch) {
         const size_t mk = arena.mark();
@@ -583,19 +590,62 @@ int pd_engine::conv(const ConvW& c, const Act& in, Act& out, int act, float scal
     return gemm(c.m, in, out, c.stride, ups, act, scale, R, rowvec, rowvec_stride, false, nullptr, 0, 0);
 }
 
-int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu) {
-    if (arena.dry) return 0;
+int pd_engine::gn_stats(const Act& x, int& nchunk) {
     const int HW = x.H * x.W;
-    int nchunk = HW / 8;   // enough blocks to fill the chip at the 8x8 / 16x16 levels too
+    nchunk = HW / 8;   // enough blocks to fill the chip at the 8x8 / 16x16 levels too
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 64) nchunk = 64;
     while ((size_t)x.B * nchunk * 32 * 2 * sizeof(double) > gn_partial_cap && nchunk > 1) nchunk /= 2;
-    launches += 2;
-    if (launch_gn_stats(x.p, x.dt, gn_partial, x.B, HW, x.C, 32, nchunk, stream) ||
-        launch_gn_apply(x.p, x.dt, y.p, y.dt, gn_partial, g, b, x.B, HW, x.C, 32, nchunk, eps, silu ? 1 : 0, stream)) {
+    if (arena.dry) return 0;
+    ++launches;
+    if (launch_gn_stats(x.p, x.dt, gn_partial, x.B, HW, x.C, 32, nchunk, stream)) {
+        pd_set_error("groupnorm stats launch failed (C=%d)", x.C);
+        return 1;
+    }
+    return 0;
+}
+
+int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu) {
+    int nchunk = 1;
+    PD_TRY(gn_stats(x, nchunk));
+    if (arena.dry) return 0;
+    ++launches;
+    if (launch_gn_apply(x.p, x.dt, y.p, y.dt, gn_partial, g, b, x.B, x.H * x.W, x.C, 32, nchunk, eps, silu ? 1 : 0, stream)) {
         pd_set_error("groupnorm launch failed (C=%d)", x.C);
         return 1;
     }
+    return 0;
+}
+
+// conv3x3(act(GroupNorm(x))): when the conv runs on the LDS-patch kernel the normalisation (+SiLU) is applied while
+// the input patch is staged, so the normalised tensor is never written to HBM; otherwise GroupNorm runs as its own pass.
+int pd_engine::conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, const float* b, float eps, bool silu,
+                       const Act* R, const float* rowvec, int rowvec_stride) {
+    GemmParams q{};
+    q.M = (int)out.rows(); q.N = c.m.N; q.K = c.m.K; q.taps = c.m.taps; q.Cin = c.m.cin_pad; q.stride = c.stride;
+    q.Hin = x.H; q.Win = x.W; q.Hout = out.H; q.Wout = out.W; q.a_dt = x.dt; q.vt_begin = INT_MAX; q.splitk = 1;
+    const bool fuse = opt_gn_fuse && opt_patch && x.C == c.m.cin_pad && conv_patch_tiles(q, f32) >= 192;
+    if (!fuse) {
+        const size_t mk = arena.mark();
+        Act a = new_act(x.B, x.H, x.W, x.C, T);
+        PD_TRY(groupnorm(x, a, g, b, eps, silu));
+        PD_TRY(conv(c, a, out, 0, 1.f, R, rowvec, rowvec_stride));
+        arena.release(mk);
+        return 0;
+    }
+    int nchunk = 1;
+    PD_TRY(gn_stats(x, nchunk));
+    const size_t mk = arena.mark();
+    float* coef = reinterpret_cast<float*>(arena.alloc((size_t)x.B * x.C * 2 * sizeof(float)));
+    if (!arena.dry) {
+        ++launches;
+        if (launch_gn_coef(gn_partial, g, b, coef, x.B, x.H * x.W, x.C, 32, nchunk, eps, stream)) {
+            pd_set_error("groupnorm coefficient launch failed");
+            return 1;
+        }
+    }
+    PD_TRY(gemm(c.m, x, out, c.stride, 0, 0, 1.f, R, rowvec, rowvec_stride, false, nullptr, 0, 0, 0, coef, silu));
+    arena.release(mk);
     return 0;
 }
 
@@ -642,18 +692,14 @@ int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const v
 int pd_engine::resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride) {
     out = new_act(x.B, x.H, x.W, r.cout, S);
     const size_t mk = arena.mark();
-    Act a = new_act(x.B, x.H, x.W, x.C, T);
-    PD_TRY(groupnorm(x, a, r.gn1_g, r.gn1_b, 1e-5f, true));
     Act h = new_act(x.B, x.H, x.W, r.cout, T);
-    PD_TRY(conv(r.conv1, a, h, 0, 1.f, nullptr, embrow, emb_stride));
-    Act a2 = new_act(x.B, x.H, x.W, r.cout, T);
-    PD_TRY(groupnorm(h, a2, r.gn2_g, r.gn2_b, 1e-5f, true));
+    PD_TRY(conv_gn(r.conv1, x, h, r.gn1_g, r.gn1_b, 1e-5f, true, nullptr, embrow, emb_stride));
     Act skip = x;
     if (r.has_skip) {
         skip = new_act(x.B, x.H, x.W, r.cout, S);
         PD_TRY(conv(r.skip, x, skip));
     }
-    PD_TRY(conv(r.conv2, a2, out, 0, 1.f, &skip));
+    PD_TRY(conv_gn(r.conv2, h, out, r.gn2_g, r.gn2_b, 1e-5f, true, &skip, nullptr, 0));
     arena.release(mk);
     return 0;
 }
@@ -798,10 +844,8 @@ int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_
         }
         h = o;
     }
-    Act a = new_act(h.B, h.H, h.W, h.C, T);
-    PD_TRY(groupnorm(h, a, n.out_g, n.out_b, 1e-5f, true));
     eps = new_act(h.B, h.H, h.W, round_up(cfg.out_channels, 4), DT_F32);
-    PD_TRY(conv(n.outconv, a, eps));
+    PD_TRY(conv_gn(n.outconv, h, eps, n.out_g, n.out_b, 1e-5f, true, nullptr, nullptr, 0));
     return 0;
 }
 

@@ -181,6 +181,9 @@ struct pd_engine {
     int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
     bool opt_bigtile = true;  // 256-row GEMM tiles where the grid still fills the chip
+    // apply GroupNorm(+SiLU) inside the patch conv's staging.  Measured neutral-to-negative in round 1 (the SiLU VALU work
+    // lands on the MFMA waves and the halo is transformed 1.27x redundantly), so it is off by default.
+    bool opt_gn_fuse = false;
     bool opt_patch = true;  // use the LDS-patch conv3x3 kernel where eligible
     long long launches = 0;
     // optional per-launch timing (bench.py roofline leg): HIP events around every contraction launch
@@ -217,7 +220,11 @@ struct pd_engine {
     // primitive ops (enqueue on stream; honour arena.dry)
     Act new_act(int B, int H, int W, int C, int dt);
     int gemm(const WMat& m, const Act& in, Act& out, int taps_stride, int ups, int act, float scale, const Act* R,
-             const float* rowvec, int rowvec_stride, bool a_silu, void* VT, int vt_begin, int vt_ld, int ldc_override = 0);
+             const float* rowvec, int rowvec_stride, bool a_silu, void* VT, int vt_begin, int vt_ld, int ldc_override = 0,
+             const float* gn_coef = nullptr, bool gn_silu = false);
+    int gn_stats(const Act& x, int& nchunk);
+    int conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, const float* b, float eps, bool silu, const Act* R,
+                const float* rowvec, int rowvec_stride);
     int conv(const ConvW& c, const Act& in, Act& out, int act = 0, float scale = 1.f, const Act* R = nullptr,
              const float* rowvec = nullptr, int rowvec_stride = 0, int ups = 0);
     int groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu);

@@ -168,6 +168,37 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
     }
 }
 
+// Folds the GroupNorm statistics and affine parameters into per-(sample, channel) coefficients
+// coef[b][c] = {a, b} with y = x * a + b, consumed by the conv kernels that normalise while staging.
+__global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ coef, int HW, int C,
+                                                      int groups, int nchunk, float eps) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < groups) {
+        double s = 0.0, q = 0.0;
+        for (int c = 0; c < nchunk; ++c) {
+            const double* o = partial + (((size_t)b * nchunk + c) * groups + tid) * 2;
+            s += o[0];
+            q += o[1];
+        }
+        const double n = (double)HW * (double)(C / groups);
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float a = s_rstd[g] * gamma[c];
+        coef[((size_t)b * C + c) * 2] = a;
+        coef[((size_t)b * C + c) * 2 + 1] = beta[c] - s_mean[g] * a;
+    }
+}
+
 // one wave per row; C <= 64*MAXV*4
 template <bool XF32, bool YF32, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, void* __restrict__ y,
@@ -245,6 +276,12 @@ int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* pa
     else if (y_dt == DT_F32) GN_AP(false, true);
     else GN_AP(false, false);
 #undef GN_AP
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_gn_coef(const double* partial, const float* gamma, const float* beta, float* coef, int B, int HW, int C, int groups,
+                   int nchunk, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(B), dim3(256), 0, s, partial, gamma, beta, coef, HW, C, groups, nchunk, eps);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

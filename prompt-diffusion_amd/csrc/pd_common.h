@@ -98,6 +98,8 @@ struct GemmParams {
     int splitk;           // >1: grid.y slices K; each slice stores an fp32 slab, a finalize pass sums them + epilogue
     void* slab;           // [splitk][M][N] fp32 workspace
     int big_tile;         // 1: 256 x 160 block tile (8 waves) instead of 128 x 160
+    const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
+    int gn_silu;
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
@@ -120,6 +122,8 @@ int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s);
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
                     const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s);
+int launch_gn_coef(const double* partial, const float* gamma, const float* beta, float* coef, int B, int HW, int C, int groups,
+                   int nchunk, float eps, hipStream_t s);
 int launch_layernorm(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta,
                      int rows, int C, float eps, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, void* out, int out_dt, int B, int C, int H, int W, int Cpad, hipStream_t s);

@@ -123,6 +123,20 @@ def test_tiny_bf16(golden_dir, tiny_bf16, tag):
     assert max(errs) < 5e-2
 
 
+def test_fused_groupnorm_option_matches(golden_dir):
+    """Option 'gn_fuse': GroupNorm(+SiLU) applied inside the patch conv's LDS staging (SD1.5 shapes are patch-eligible)."""
+    g = np.load(os.path.join(golden_dir, "net_sd15_b1_32x32_s5.npz"))
+    e = _engine(W.SD15, "f32")
+    e.set_option("gn_fuse", 1)
+    inp, x_in, t_in, ctx, pair, qry = _cfg_inputs(W.SD15, g)
+    # batch 2 x 32x32 gives 8 patches x 2 n-tiles = 16 blocks (< 192): widen the batch so the patch kernel is chosen
+    rep = 12
+    eps = e.eps(np.tile(x_in, (rep, 1, 1, 1)), np.tile(t_in, rep), np.tile(ctx, (rep, 1, 1)), np.tile(pair, (rep, 1, 1, 1)),
+                np.tile(qry, (rep, 1, 1, 1)))
+    assert relerr(eps[:2], g["eps"]) < 2e-4 and relerr(eps[-2:], g["eps"]) < 2e-4
+    e.close()
+
+
 def test_stepwise_equals_fused(tiny_f32):
     inp = W.synth_inputs(W.TINY, 1, 8, 8)
     kw = dict(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"],
