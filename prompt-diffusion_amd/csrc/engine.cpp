@@ -531,6 +531,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.slab = nullptr;
     p.gn_coef = gn_coef;
     p.gn_silu = gn_silu ? 1 : 0;
+    p.diag = opt_diag;
     // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
     const bool use_patch = opt_patch && conv_patch_tiles(p, f32) >= 192;
     if (gn_coef && !use_patch) {
@@ -556,6 +557,13 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         p.splitk = splitk;
         // 256-row tiles when they still give every CU a block (1 block of 8 waves per CU)
         p.big_tile = (opt_bigtile && splitk == 1 && ((p.M + 255) / 256) * ((m.N + 159) / 160) >= 256) ? 1 : 0;
+        if (opt_dense_k > 0 && ktiles <= opt_dense_k && m.taps == 1) p.big_tile = 2;
+        // 256 x 320 tiles for linear layers that still give (almost) every CU a block
+        {
+            const int t3 = ((p.M + 255) / 256) * ((m.N + 319) / 320);
+            const int rounds = (t3 + 255) / 256;
+            if (opt_wide && splitk == 1 && m.taps == 1 && in.dt == T && t3 >= 256 && t3 * 100 >= rounds * 256 * 85) p.big_tile = 3;
+        }
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
     }
     if (arena.dry) return 0;

@@ -180,6 +180,9 @@ struct pd_engine {
     int verbose = 0;
     int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
+    int opt_diag = 0;          // timing diagnostic (wrong results): GEMM operands all read row 0
+    bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
+    int opt_dense_k = 0;       // linear layers with at most this many K steps use the 16-waves-per-CU tile shape
     bool opt_bigtile = true;  // 256-row GEMM tiles where the grid still fills the chip
     // apply GroupNorm(+SiLU) inside the patch conv's staging.  Measured neutral-to-negative in round 1 (the SiLU VALU work
     // lands on the MFMA waves and the halo is transformed 1.27x redundantly), so it is off by default.

@@ -25,7 +25,10 @@
 
 namespace {
 
-constexpr int BN = 160, BKB = 128;  // tile columns; BKB = bytes of K per LDS row
+constexpr int BKB = 128;  // bytes of K per LDS row
+// Block shapes (BM x BN): 128 x 160 (4 or 8 waves), 256 x 160 (8 waves) and 256 x 320 (8 waves, 160 accumulator
+// registers per lane).  The generic kernel is bound by operand bytes fetched per FLOP (~1/BM + 1/BN) against the ~6 TB/s
+// the CUs can pull from L2, so large-M layers use the biggest tile that still fills the chip.
 // Two block shapes: 128 x 160 with 4 waves (2 blocks per CU) and 256 x 160 with 8 waves (1 block per CU,
 // 1.4x fewer operand bytes per FLOP) for layers with enough rows to fill the chip with the big tile.
 
@@ -33,11 +36,11 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row * BKB) + ((
 
 // F32: fp32 MFMA mode.  CONV: 3x3 gather (else rows of A are contiguous).  AF32: bf16 compute with an
 // fp32 A source (converted while staging; only meaningful when !F32).
-template <bool F32, int BM, int WM, int WN, bool CONV, bool AF32>
-__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(GemmParams p) {
+template <bool F32, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
+__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) void igemm_kernel(GemmParams p) {
     // register prefetch depth: two K steps ahead (two named staging sets) unless the fp32->bf16 staging
     // path already doubles the A registers
-    constexpr int DEPTH = AF32 ? 1 : 2;
+    constexpr int DEPTH = (AF32 || BN > 160 || (BM == 128 && WM * WN == 8)) ? 1 : 2;   // the 16-waves-per-CU shape has 128 VGPRs per wave
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int A_ITERS = BM * 8 / NTHREADS;                   // 16-byte chunks per thread per K step
     constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;  // last one masked when it does not divide
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(GemmParams p) {
             a_x[i] = (rem - oy * p.Wout) * p.stride - 1;
             a_base[i] = 0;
         } else {
-            a_base[i] = (size_t)mm * p.lda;
+            a_base[i] = (size_t)(p.diag ? 0 : mm) * p.lda;
             a_pix[i] = a_y[i] = a_x[i] = 0;
         }
     }
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(GemmParams p) {
     for (int i = 0; i < B_ITERS; ++i) {
         int n = bn * BN + row0 + ROWS_PER_IT * i;
         n = n < p.N ? n : p.N - 1;  // clamp: columns >= N are never stored
-        w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)n * p.Kpad + chunk * VEC) * EB;
+        w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(p.diag ? 0 : n) * p.Kpad + chunk * VEC) * EB;
     }
 
     const int ktiles_all = p.Kpad / BKE;
@@ -290,21 +293,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(GemmParams p) {
         const int tok = gm - sample * p.rows_per_sample;
         if (p.act == 2) {
             // GEGLU: virtual columns [0,80) of this tile are x, [80,160) the gate (weights interleaved at load)
-            if constexpr (NT == 10) {
+            if constexpr (NT % 10 == 0 && WN == 1) {
 #pragma unroll
-                for (int n = 0; n < 5; ++n) {
-                    const int vn = bn * BN + n * 16 + fq * 4;
-                    const int on = bn * (BN / 2) + n * 16 + fq * 4;
-                    if (on >= p.Nout) continue;
-                    f32x4 x = acc[n][m], g = acc[n + 5][m];
-                    if (p.bias) {
-                        x += *reinterpret_cast<const f32x4*>(p.bias + vn);
-                        g += *reinterpret_cast<const f32x4*>(p.bias + vn + BN / 2);
+                for (int sb = 0; sb < NT / 10; ++sb) {   // 160-column sub-blocks: [80 x | 80 gate]
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) {
+                        const int vn = bn * BN + sb * 160 + n * 16 + fq * 4;
+                        const int on = (bn * (BN / 160) + sb) * 80 + n * 16 + fq * 4;
+                        if (on >= p.Nout) continue;
+                        f32x4 x = acc[sb * 10 + n][m], g = acc[sb * 10 + n + 5][m];
+                        if (p.bias) {
+                            x += *reinterpret_cast<const f32x4*>(p.bias + vn);
+                            g += *reinterpret_cast<const f32x4*>(p.bias + vn + 80);
+                        }
+                        f32x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = x[j] * (F32 ? gelu_f(g[j]) : gelu_fast(g[j]));
+                        store4(p.C, (size_t)gm * p.ldc + on, p.c_dt, o);
                     }
-                    f32x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = x[j] * (F32 ? gelu_f(g[j]) : gelu_fast(g[j]));
-                    store4(p.C, (size_t)gm * p.ldc + on, p.c_dt, o);
                 }
             }
             continue;
@@ -333,12 +339,12 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
     }
 }
 
-template <bool F32, int BM, int WM, int WN, bool CONV, bool AF32>
+template <bool F32, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
 int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB;
     static bool attr_done = false;
-    auto kfn = igemm_kernel<F32, BM, WM, WN, CONV, AF32>;
+    auto kfn = igemm_kernel<F32, BM, BN, WM, WN, CONV, AF32>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SMEM_BYTES) != hipSuccess)
@@ -362,26 +368,30 @@ int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
 
 }  // namespace
 
-int gemm_tiles(int M, int N) { return ((M + 127) / 128) * ((N + BN - 1) / BN); }
+int gemm_tiles(int M, int N) { return ((M + 127) / 128) * ((N + 159) / 160); }
 
 int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid) {
     if (p.M <= 0 || p.N <= 0) return 0;
     const bool conv = p.taps != 1;
     const bool af32 = p.a_dt == DT_F32;
     if (p.splitk > 1 && (p.act == 2 || p.vt_begin < p.N || !p.slab || p.N % 4)) return 1;
-    // big tile when it still yields at least one block per CU
-    const bool big = p.big_tile && p.splitk == 1;
+    const int tile = p.splitk == 1 ? p.big_tile : 0;   // 0: 128x160, 1: 256x160, 2: 128x160 on 8 waves, 3: 256x320
     if (p.act == 2) {
         if (conv || (!f32mode && af32)) return 1;
-        if (big) return f32mode ? launch_one<true, 256, 8, 1, false, false>(p, s, mid) : launch_one<false, 256, 8, 1, false, false>(p, s, mid);
-        return f32mode ? launch_one<true, 128, 4, 1, false, false>(p, s, mid) : launch_one<false, 128, 4, 1, false, false>(p, s, mid);
+        if (tile == 3) return f32mode ? launch_one<true, 256, 320, 8, 1, false, false>(p, s, mid) : launch_one<false, 256, 320, 8, 1, false, false>(p, s, mid);
+        if (tile == 1) return f32mode ? launch_one<true, 256, 160, 8, 1, false, false>(p, s, mid) : launch_one<false, 256, 160, 8, 1, false, false>(p, s, mid);
+        return f32mode ? launch_one<true, 128, 160, 4, 1, false, false>(p, s, mid) : launch_one<false, 128, 160, 4, 1, false, false>(p, s, mid);
     }
-    if (big) {
-        if (f32mode) return conv ? launch_one<true, 256, 4, 2, true, false>(p, s, mid) : launch_one<true, 256, 4, 2, false, false>(p, s, mid);
-        if (conv) return af32 ? launch_one<false, 256, 4, 2, true, true>(p, s, mid) : launch_one<false, 256, 4, 2, true, false>(p, s, mid);
-        return af32 ? launch_one<false, 256, 4, 2, false, true>(p, s, mid) : launch_one<false, 256, 4, 2, false, false>(p, s, mid);
+    if (tile == 3 && !conv && !af32)
+        return f32mode ? launch_one<true, 256, 320, 4, 2, false, false>(p, s, mid) : launch_one<false, 256, 320, 4, 2, false, false>(p, s, mid);
+    if (tile == 2 && !conv && !af32)
+        return f32mode ? launch_one<true, 128, 160, 4, 2, false, false>(p, s, mid) : launch_one<false, 128, 160, 4, 2, false, false>(p, s, mid);
+    if (tile == 1 || tile == 3) {
+        if (f32mode) return conv ? launch_one<true, 256, 160, 4, 2, true, false>(p, s, mid) : launch_one<true, 256, 160, 4, 2, false, false>(p, s, mid);
+        if (conv) return af32 ? launch_one<false, 256, 160, 4, 2, true, true>(p, s, mid) : launch_one<false, 256, 160, 4, 2, true, false>(p, s, mid);
+        return af32 ? launch_one<false, 256, 160, 4, 2, false, true>(p, s, mid) : launch_one<false, 256, 160, 4, 2, false, false>(p, s, mid);
     }
-    if (f32mode) return conv ? launch_one<true, 128, 2, 2, true, false>(p, s, mid) : launch_one<true, 128, 2, 2, false, false>(p, s, mid);
-    if (conv) return af32 ? launch_one<false, 128, 2, 2, true, true>(p, s, mid) : launch_one<false, 128, 2, 2, true, false>(p, s, mid);
-    return af32 ? launch_one<false, 128, 2, 2, false, true>(p, s, mid) : launch_one<false, 128, 2, 2, false, false>(p, s, mid);
+    if (f32mode) return conv ? launch_one<true, 128, 160, 2, 2, true, false>(p, s, mid) : launch_one<true, 128, 160, 2, 2, false, false>(p, s, mid);
+    if (conv) return af32 ? launch_one<false, 128, 160, 2, 2, true, true>(p, s, mid) : launch_one<false, 128, 160, 2, 2, true, false>(p, s, mid);
+    return af32 ? launch_one<false, 128, 160, 2, 2, false, true>(p, s, mid) : launch_one<false, 128, 160, 2, 2, false, false>(p, s, mid);
 }

@@ -100,6 +100,7 @@ struct GemmParams {
     int big_tile;         // 1: 256 x 160 block tile (8 waves) instead of 128 x 160
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;
+    int diag;             // timing diagnostic: every tile row reads row 0 (operands served from L1); results are wrong
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
