@@ -307,6 +307,13 @@ int pd_engine::build() {
     }
     gn_partial_cap = 8u << 20;
     gn_partial = reinterpret_cast<double*>(dmalloc(gn_partial_cap));
+    gn_partial2 = reinterpret_cast<double*>(dmalloc(gn_partial_cap));
+    if (hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking) != hipSuccess) stream2 = nullptr;
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+        pd_set_error("hipEventCreate failed");
+        return 1;
+    }
     for (void* p : owned)
         if (!p) {
             pd_set_error("hipMalloc failed while building the engine (%zu bytes so far)", weight_bytes);
@@ -821,6 +828,7 @@ int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_
     PD_TRY(transformer(n.mid1, m0, m1, ses.kv_u[n.mid1.kv_slot]));
     PD_TRY(resblock(n.mid2, m1, m2, emb_ptr(ses.emb_u, n.mid2, emb_row), emb_stride ? n.mid2.cout : 0));
     h = m2;
+    PD_TRY(join_controlnet());   // the decoder is the first consumer of the control tensors
     const int nctl = (int)cnet.enc.size();  // index of the middle control tensor
     for (size_t i = 0; i < n.dec.size(); ++i) {
         DecBlock& b = n.dec[i];
@@ -857,6 +865,28 @@ int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_
     return 0;
 }
 
+void pd_engine::swap_context() {
+    std::swap(arena, arena2);
+    std::swap(stream, stream2);
+    std::swap(gn_partial, gn_partial2);
+}
+
+// Called by the UNet right before its decoder: wait for the ControlNet stream, then apply the guess-mode zeroing.
+int pd_engine::join_controlnet() {
+    const pd_sample_args& a = ses.a;
+    if (arena.dry) return 0;
+    if (cn_pending) {
+        HIP_OK(hipStreamWaitEvent(stream, ev_join, 0));
+        cn_pending = false;
+    }
+    if (a.guess_mode && a.use_cfg) {
+        // (D) pipeline :1248-1253: the unconditional half gets zero residuals
+        for (size_t i = 0; i <= cnet.enc.size(); ++i)
+            HIP_OK(hipMemsetAsync(ses.control[i].p, 0, ses.control[i].bytes() / 2, stream));
+    }
+    return 0;
+}
+
 // ControlLDM.apply_model, cldm/cldm.py:369-382
 int pd_engine::forward_eps(int emb_row, int emb_stride, const float* scales, Act& eps) {
     const pd_sample_args& a = ses.a;
@@ -870,14 +900,24 @@ int pd_engine::forward_eps(int emb_row, int emb_stride, const float* scales, Act
         ses.control[i] = new_act(Bf, hh, ww, cnet.enc[i].cout, S);
     }
     ses.control[cnet.enc.size()] = new_act(Bf, hh, ww, cnet.enc.back().cout, S);
-    const size_t mk = arena.mark();
-    PD_TRY(run_controlnet(x_in, emb_row, emb_stride, scales));
-    arena.release(mk);
-    if (a.guess_mode && a.use_cfg && !arena.dry) {
-        // (D) pipeline :1248-1253: the unconditional half gets zero residuals
-        for (size_t i = 0; i <= cnet.enc.size(); ++i)
-            HIP_OK(hipMemsetAsync(ses.control[i].p, 0, ses.control[i].bytes() / 2, stream));
+    // ControlNet and the UNet encoder + middle block are independent: ControlNet is enqueued on a second stream with its
+    // own workspace so that its kernels overlap the encoder's (different kernels meet on a CU in different phases: MFMA
+    // main loops next to VALU-heavy epilogues / softmax).  The decoder waits for it (join_controlnet).
+    const bool two = opt_two_streams && stream2 != nullptr;
+    if (two && !arena.dry) {
+        HIP_OK(hipEventRecord(ev_fork, stream));
+        HIP_OK(hipStreamWaitEvent(stream2, ev_fork, 0));
     }
+    if (two) swap_context();
+    const size_t mk = arena.mark();
+    int rc = run_controlnet(x_in, emb_row, emb_stride, scales);
+    arena.release(mk);
+    if (two) {
+        if (!rc && !arena.dry && hipEventRecord(ev_join, stream) != hipSuccess) rc = 1;   // `stream` is stream2 here
+        swap_context();
+    }
+    if (rc) return rc;
+    cn_pending = two;
     PD_TRY(run_unet(x_in, emb_row, emb_stride, a.only_mid_control != 0, eps));
     return 0;
 }

@@ -176,6 +176,15 @@ struct pd_engine {
     std::vector<void*> owned;  // device allocations (weights)
     size_t weight_bytes = 0;
     Arena arena;
+    // second context for the ControlNet pass (own stream / workspace / GroupNorm scratch), see forward_eps
+    Arena arena2;
+    hipStream_t stream2 = nullptr;
+    double* gn_partial2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool cn_pending = false;
+    bool opt_two_streams = true;
+    void swap_context();
+    int join_controlnet();
     Session ses;
     int verbose = 0;
     int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this

@@ -220,34 +220,45 @@ int pd_engine::session_setup(const pd_sample_args& a, const int64_t* t_rows, int
 }
 
 int pd_engine::ensure_arena(int Bf, int h, int w, int rows, bool per_step) {
-    (void)Bf; (void)h; (void)w; (void)rows; (void)per_step;
-    // dry run of setup + one forward to size the arena
-    Arena saved = arena;
+    (void)Bf; (void)h; (void)w;
+    // dry run of setup + one forward to size both workspaces (main and ControlNet context)
+    Arena saved = arena, saved2 = arena2;
     arena.base = nullptr; arena.cap = 0; arena.top = 0; arena.peak = 0; arena.dry = true;
+    arena2.base = nullptr; arena2.cap = 0; arena2.top = 0; arena2.peak = 0; arena2.dry = true;
     std::vector<int64_t> t(rows, 1);
     int r = session_setup(ses.a, t.data(), rows, false, per_step);
     Act eps;
     if (!r) r = forward_eps(0, 0, nullptr, eps);
-    const size_t need = arena.peak + (64u << 20);
+    const size_t need = arena.peak + (64u << 20), need2 = arena2.peak + (64u << 20);
     arena = saved;
+    arena2 = saved2;
     arena.dry = false;
+    arena2.dry = false;
+    cn_pending = false;
     if (r) return r;
-    if (need > arena.cap) {
-        HIP_OK(hipStreamSynchronize(stream));
-        if (arena.base) HIP_OK(hipFree(arena.base));
-        arena.base = nullptr;
-        arena.cap = 0;
+    auto grow = [&](Arena& a, size_t want, const char* what) -> int {
+        if (want <= a.cap) return 0;
+        if (a.base) HIP_OK(hipFree(a.base));
+        a.base = nullptr;
+        a.cap = 0;
         void* p = nullptr;
-        if (hipMalloc(&p, need) != hipSuccess) {
-            pd_set_error("workspace allocation of %.2f GiB failed", (double)need / (1 << 30));
+        if (hipMalloc(&p, want) != hipSuccess) {
+            pd_set_error("%s workspace allocation of %.2f GiB failed", what, (double)want / (1 << 30));
             return 1;
         }
-        arena.base = reinterpret_cast<char*>(p);
-        arena.cap = need;
-        if (verbose) fprintf(stderr, "[pdengine] workspace %.2f GiB\n", (double)need / (1 << 30));
+        a.base = reinterpret_cast<char*>(p);
+        a.cap = want;
+        if (verbose) fprintf(stderr, "[pdengine] %s workspace %.2f GiB\n", what, (double)want / (1 << 30));
+        return 0;
+    };
+    if (need > arena.cap || need2 > arena2.cap) {
+        HIP_OK(hipStreamSynchronize(stream));
+        if (stream2) HIP_OK(hipStreamSynchronize(stream2));
+        PD_TRY(grow(arena, need, "main"));
+        PD_TRY(grow(arena2, need2, "controlnet"));
     }
-    arena.top = 0;
-    arena.peak = 0;
+    arena.top = 0; arena.peak = 0;
+    arena2.top = 0; arena2.peak = 0;
     return 0;
 }
 
@@ -358,6 +369,10 @@ void pd_engine_destroy(pd_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
+    if (e->arena2.base) hipFree(e->arena2.base);
     for (void* p : e->owned)
         if (p) hipFree(p);
     if (e->arena.base) hipFree(e->arena.base);
@@ -559,6 +574,7 @@ int pd_ddim_sample(pd_engine* e, const pd_sample_args* args, int32_t mem_out, fl
 int pd_synchronize(pd_engine* e) {
     if (!e) { pd_set_error("null engine"); return 1; }
     HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->stream2) HIP_OK(hipStreamSynchronize(e->stream2));
     return 0;
 }
 
@@ -571,6 +587,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "splitk_tiles")) { e->opt_splitk_tiles = (int)value; return 0; }
     if (!strcmp(key, "attn_legacy")) { e->opt_attn_legacy = value != 0; return 0; }
     if (!strcmp(key, "gn_fuse")) { e->opt_gn_fuse = value != 0; return 0; }
+    if (!strcmp(key, "two_streams")) { e->opt_two_streams = value != 0; return 0; }
     if (!strcmp(key, "diag")) { e->opt_diag = (int)value; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
     if (!strcmp(key, "dense_k")) { e->opt_dense_k = (int)value; return 0; }
@@ -600,6 +617,7 @@ int64_t pd_get_stat(pd_engine* e, const char* key) {
 int pd_profile_read(pd_engine* e, int32_t klass, double* total_ms, int64_t* n_launches, double* flops) {
     if (!e) { pd_set_error("null engine"); return 1; }
     HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->stream2) HIP_OK(hipStreamSynchronize(e->stream2));
     double ms = 0.0, fl = 0.0;
     int64_t n = 0;
     for (auto& r : e->prof) {
@@ -617,6 +635,7 @@ int pd_profile_read(pd_engine* e, int32_t klass, double* total_ms, int64_t* n_la
 int pd_profile_dump(pd_engine* e, const char* path) {
     if (!e || !path) { pd_set_error("null argument"); return 1; }
     HIP_OK(hipStreamSynchronize(e->stream));
+    if (e->stream2) HIP_OK(hipStreamSynchronize(e->stream2));
     FILE* f = fopen(path, "w");
     if (!f) { pd_set_error("cannot open %s", path); return 1; }
     fprintf(f, "klass,M,N,K,taps,ms,flops\n");
