@@ -175,6 +175,17 @@ def main():
                                   "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": traffic, "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,
                                   "flop_per_launch": 1e9 * fl_g / max(n_g, 1), "device_ms_per_pass": ms_g, "by_kernel": classes}
+        # first-stage decode of the 8 latents, outside the metric's timed region: reported for context
+        try:
+            eng.vae_decode(out[:B])
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            img = eng.vae_decode(out[:B])
+            torch.cuda.synchronize()
+            result["vae_decode_ms"] = 1e3 * (time.perf_counter() - tv)
+            assert torch.isfinite(img).all()
+        except Exception as ex:   # noqa: BLE001 - context only
+            result["vae_decode_ms"] = f"failed: {ex}"
         if not args.no_f32 and world == 1 and args.precision == "bf16":
             # the engine's fp32 mode (v_mfma_f32_16x16x4_f32: the mode that meets the 1e-3 per-step parity bound, 2e-4
             # measured) on the same workload: 1 warm-up + 1 timed pass

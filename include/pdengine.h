@@ -65,6 +65,13 @@ typedef struct pd_config {
     double linear_end;        /* 0.0120 */
     int32_t precision;        /* PD_PREC_* */
     int32_t stream_f32;       /* PD_PREC_BF16 only: keep the residual stream (block outputs) in fp32 */
+    /* first-stage KL-VAE decoder (models/cldm_v15.yaml:64-85).  vae_ch = 0: not built */
+    int32_t vae_ch;           /* 128 */
+    int32_t vae_num_levels;   /* 4 */
+    int32_t vae_ch_mult[PD_MAX_LEVELS]; /* 1,2,4,4 */
+    int32_t vae_num_res_blocks; /* 2 */
+    int32_t vae_out_ch;       /* 3 */
+    double scale_factor;      /* 0.18215, cldm_v15.yaml:17 */
     int32_t reserved[6];
 } pd_config;
 
@@ -112,8 +119,15 @@ int pd_load_weights(pd_engine* e, const char* name, const void* data, const int6
                     int32_t ndim, int32_t dtype);
 /* device-side seeded N(0, 1/fan_in)-style initialisation of every tensor (benchmarks only) */
 int pd_init_random_weights(pd_engine* e, uint64_t seed);
-/* number of tensors not loaded yet (0 = ready) */
+/* number of UNet + ControlNet tensors not loaded yet (0 = ready to sample); the VAE decoder is counted separately */
 int pd_weights_missing(pd_engine* e);
+int pd_vae_weights_missing(pd_engine* e);
+
+/* first-stage decode, LatentDiffusion.decode_first_stage (ldm/models/diffusion/ddpm.py:820-828) ->
+ * AutoencoderKL.decode (ldm/models/autoencoder.py:89-92) -> Decoder.forward (ldm/modules/diffusionmodules/model.py:619-653):
+ * latents [B, in_ch, h, w] -> images [B, vae_out_ch, 8h, 8w] in roughly [-1, 1] (fp32, NCHW).  Call after the sampling
+ * session has ended; parameters are the checkpoint's first_stage_model.decoder.* / first_stage_model.post_quant_conv.* */
+int pd_vae_decode(pd_engine* e, const float* latents, int32_t B, int32_t h, int32_t w, int32_t mem, float* images_out);
 
 /* operator boundary: eps = apply_model(x, t, cond), cldm/cldm.py:369-382.
  *   x [Bf,in_ch,h,w], t [Bf] (int64), ctx [Bf,L,D], pair [Bf,hint_ch,8h,8w], query [Bf,q_ch,8h,8w],

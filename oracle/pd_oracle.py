@@ -359,3 +359,51 @@ def make_layouts(cfg, weights_mod):
     return dict(enc=weights_mod.encoder_layout(cfg), dec=weights_mod.decoder_layout(cfg),
                 hint_pair=weights_mod.hint_layout(cfg, cfg.hint_channels),
                 hint_query=weights_mod.hint_layout(cfg, cfg.query_channels))
+
+
+# ----------------------------------------------------------------------------- first-stage decoder
+def vae_resnet_block(p: Net, pre: str, x):
+    """ResnetBlock.forward with temb=None, ldm/modules/diffusionmodules/model.py:121-141 (GroupNorm eps 1e-6, :41-42)."""
+    h = conv2d(silu(group_norm(x, p(pre + "norm1.weight"), p(pre + "norm1.bias"), eps=1e-6)),
+               p(pre + "conv1.weight"), p(pre + "conv1.bias"))
+    h = conv2d(silu(group_norm(h, p(pre + "norm2.weight"), p(pre + "norm2.bias"), eps=1e-6)),
+               p(pre + "conv2.weight"), p(pre + "conv2.bias"))
+    if p.has(pre + "nin_shortcut.weight"):
+        x = conv2d(x, p(pre + "nin_shortcut.weight"), p(pre + "nin_shortcut.bias"), padding=0)
+    return x + h
+
+
+def vae_attn_block(p: Net, pre: str, x):
+    """AttnBlock.forward (single head over all channels), model.py:171-202."""
+    B, C, H, W = x.shape
+    h = group_norm(x, p(pre + "norm.weight"), p(pre + "norm.bias"), eps=1e-6)
+    q = conv2d(h, p(pre + "q.weight"), p(pre + "q.bias"), padding=0).reshape(B, C, H * W).transpose(0, 2, 1)
+    k = conv2d(h, p(pre + "k.weight"), p(pre + "k.bias"), padding=0).reshape(B, C, H * W)
+    v = conv2d(h, p(pre + "v.weight"), p(pre + "v.bias"), padding=0).reshape(B, C, H * W)
+    w_ = np.matmul(q, k) * F32(int(C) ** (-0.5))
+    w_ = w_ - w_.max(axis=2, keepdims=True)
+    e = np.exp(w_)
+    w_ = e / e.sum(axis=2, keepdims=True)
+    h = np.matmul(v, w_.transpose(0, 2, 1)).reshape(B, C, H, W)
+    h = conv2d(h, p(pre + "proj_out.weight"), p(pre + "proj_out.bias"), padding=0)
+    return x + h
+
+
+def vae_decode(sd, cfg, vae_layout, z):
+    """LatentDiffusion.decode_first_stage (ddpm.py:820-828: z / scale_factor) -> AutoencoderKL.decode
+    (autoencoder.py:89-92: post_quant_conv, decoder) -> Decoder.forward (model.py:619-653)."""
+    p = Net(sd, "first_stage_model.")
+    z = (F32(1.0) / F32(cfg.scale_factor) * z).astype(F32)
+    z = conv2d(z, p("post_quant_conv.weight"), p("post_quant_conv.bias"), padding=0)
+    h = conv2d(z, p("decoder.conv_in.weight"), p("decoder.conv_in.bias"))
+    h = vae_resnet_block(p, "decoder.mid.block_1.", h)
+    h = vae_attn_block(p, "decoder.mid.attn_1.", h)
+    h = vae_resnet_block(p, "decoder.mid.block_2.", h)
+    for lvl in vae_layout:  # execution order: highest level first
+        for j in range(len(lvl["blocks"])):
+            h = vae_resnet_block(p, f"decoder.up.{lvl['level']}.block.{j}.", h)
+        if lvl["upsample"]:
+            h = np.repeat(np.repeat(h, 2, axis=2), 2, axis=3)   # F.interpolate(scale_factor=2.0, mode="nearest"), :62
+            h = conv2d(h, p(f"decoder.up.{lvl['level']}.upsample.conv.weight"), p(f"decoder.up.{lvl['level']}.upsample.conv.bias"))
+    h = silu(group_norm(h, p("decoder.norm_out.weight"), p("decoder.norm_out.bias"), eps=1e-6))
+    return conv2d(h, p("decoder.conv_out.weight"), p("decoder.conv_out.bias"))

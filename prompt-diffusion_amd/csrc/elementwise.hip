@@ -14,16 +14,40 @@ inline int nblocks(long long n, int per = TPB, int cap = 65535 * 16) {
 }
 
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, void* __restrict__ out, int out_dt, int B, int C,
-                                    int HW, int Cpad) {
+                                    int HW, int Cpad, float scale) {
     const long long total = (long long)B * HW * Cpad;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % Cpad);
         const long long bp = i / Cpad;
         const int p = (int)(bp % HW);
         const int b = (int)(bp / HW);
-        const float v = c < C ? in[((long long)b * C + c) * HW + p] : 0.f;
+        const float v = c < C ? scale * in[((long long)b * C + c) * HW + p] : 0.f;
         if (out_dt == DT_F32) reinterpret_cast<float*>(out)[i] = v;
         else reinterpret_cast<uint16_t*>(out)[i] = f2bf(v);
+    }
+}
+
+// row softmax of fp32 logits (one wave per row), output in the compute type: the VAE's single-head attention
+// (AttnBlock, model.py:171-202) materialises its [N, N] scores like the reference does
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, void* __restrict__ out, int out_dt,
+                                                            int rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = in + (size_t)row * n;
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, x[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += __expf(x[i] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < n; i += 64) {
+        const float v = __expf(x[i] - m) * inv;
+        if (out_dt == DT_F32) reinterpret_cast<float*>(out)[(size_t)row * n + i] = v;
+        else reinterpret_cast<uint16_t*>(out)[(size_t)row * n + i] = f2bf(v);
     }
 }
 
@@ -166,9 +190,13 @@ __global__ void fill_random_kernel(void* __restrict__ p, int dt, long long n, fl
 
 #define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? 0 : 1
 
-int launch_nchw_to_nhwc(const float* in, void* out, int out_dt, int B, int C, int H, int W, int Cpad, hipStream_t s) {
+int launch_nchw_to_nhwc(const float* in, void* out, int out_dt, int B, int C, int H, int W, int Cpad, hipStream_t s, float scale) {
     const long long n = (long long)B * H * W * Cpad;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks(n)), dim3(TPB), 0, s, in, out, out_dt, B, C, H * W, Cpad);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks(n)), dim3(TPB), 0, s, in, out, out_dt, B, C, H * W, Cpad, scale);
+    CHECK_LAUNCH();
+}
+int launch_softmax_rows(const float* in, void* out, int out_dt, int rows, int n, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, out, out_dt, rows, n);
     CHECK_LAUNCH();
 }
 int launch_nhwc_to_nchw(const void* in, int in_dt, float* out, int B, int C, int H, int W, int Cpad, float scale, hipStream_t s) {

@@ -66,6 +66,7 @@ void pd_engine::reg_mat(const std::string& name, std::vector<int64_t> shape, WMa
     p.row_off = row_off;
     p.conv = conv;
     p.init = 'w';
+    p.group = reg_group;
     index[name] = (int)params.size();
     params.push_back(std::move(p));
 }
@@ -78,6 +79,7 @@ void pd_engine::reg_vec(const std::string& name, int n, float** dst, char init) 
     p.kind = 0;
     p.vdst = *dst;
     p.init = init;
+    p.group = reg_group;
     index[name] = (int)params.size();
     params.push_back(std::move(p));
 }
@@ -91,6 +93,7 @@ void pd_engine::reg_bias(const std::string& name, WMat* m, int off, int n, bool 
     p.geglu_vec = geglu;
     p.geglu_half = geglu ? n / 2 : 0;
     p.init = 'b';
+    p.group = reg_group;
     index[name] = (int)params.size();
     params.push_back(std::move(p));
 }
@@ -294,6 +297,7 @@ int pd_engine::build() {
         const int ch = mc * cfg.channel_mult[cfg.num_levels - 1];
         build_conv(P + "middle_block_out.0.", n.mid_out, ch, ch, 1, 1);
     }
+    build_vae();
     if ((int)cnet.enc.size() + 1 != PD_NUM_CONTROL && verbose)
         fprintf(stderr, "[pdengine] note: %zu control tensors (reference SD1.5 has 13)\n", cnet.enc.size() + 1);
     if ((int)cnet.enc.size() + 1 > PD_NUM_CONTROL) {
@@ -708,13 +712,13 @@ int pd_engine::resblock(const ResW& r, const Act& x, Act& out, const float* embr
     out = new_act(x.B, x.H, x.W, r.cout, S);
     const size_t mk = arena.mark();
     Act h = new_act(x.B, x.H, x.W, r.cout, T);
-    PD_TRY(conv_gn(r.conv1, x, h, r.gn1_g, r.gn1_b, 1e-5f, true, nullptr, embrow, emb_stride));
+    PD_TRY(conv_gn(r.conv1, x, h, r.gn1_g, r.gn1_b, r.eps, true, nullptr, embrow, emb_stride));
     Act skip = x;
     if (r.has_skip) {
         skip = new_act(x.B, x.H, x.W, r.cout, S);
         PD_TRY(conv(r.skip, x, skip));
     }
-    PD_TRY(conv_gn(r.conv2, h, out, r.gn2_g, r.gn2_b, 1e-5f, true, &skip, nullptr, 0));
+    PD_TRY(conv_gn(r.conv2, h, out, r.gn2_g, r.gn2_b, r.eps, true, &skip, nullptr, 0));
     arena.release(mk);
     return 0;
 }

@@ -50,6 +50,7 @@ struct ResW {
     ConvW conv1, conv2, skip;
     WMat emb;
     bool has_skip = false;
+    float eps = 1e-5f;  // GroupNorm eps (1e-6 in the VAE's ResnetBlock)
     int emb_slot = -1;  // index into the per-net table of projected time embeddings
 };
 
@@ -98,6 +99,23 @@ struct NetW {
     std::vector<STW*> st_list;    // in kv_slot order
 };
 
+// First-stage decoder: ldm/modules/diffusionmodules/model.py:546-653 + post_quant_conv (autoencoder.py:34)
+struct VaeLevel {
+    std::vector<ResW> blocks;
+    bool up = false;
+    ConvW upconv;
+    int ch = 0;
+};
+struct VaeW {
+    bool built = false;
+    ConvW post_quant, conv_in, conv_out, proj_out;
+    ResW mid1, mid2;
+    float *attn_g = nullptr, *attn_b = nullptr, *out_g = nullptr, *out_b = nullptr;
+    WMat qkv;
+    std::vector<VaeLevel> levels;  // execution order (highest resolution level last)
+    int top = 0;
+};
+
 struct Param {
     std::string name;
     std::vector<int64_t> shape;
@@ -112,6 +130,7 @@ struct Param {
     bool conv = false;  // OIHW source
     char init = 'w';    // recipe class for pd_init_random_weights: w, b, g(amma), e(beta)
     bool loaded = false;
+    int group = 0;      // 0: UNet + ControlNet (needed to sample), 1: VAE decoder
 };
 
 struct Act {
@@ -173,6 +192,8 @@ struct pd_engine {
     std::vector<Param> params;
     std::unordered_map<std::string, int> index;
     NetW unet, cnet;
+    VaeW vae;
+    int reg_group = 0;
     std::vector<void*> owned;  // device allocations (weights)
     size_t weight_bytes = 0;
     Arena arena;
@@ -222,6 +243,10 @@ struct pd_engine {
     void build_st(const std::string& prefix, STW& s, int ch, NetW& net);
     void build_encoder(const std::string& prefix, NetW& net);
     void build_middle(const std::string& prefix, NetW& net);
+    void build_vres(const std::string& prefix, ResW& r, int cin, int cout);
+    void build_vae();
+    int vae_forward(const float* latents_dev, int B, int h, int w, float* out_dev);
+    int vae_attention(const Act& x, Act& out);
 
     // weights
     int load(const char* name, const void* data, const int64_t* shape, int ndim, int dtype);

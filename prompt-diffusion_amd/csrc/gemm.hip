@@ -100,7 +100,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     for (int i = 0; i < B_ITERS; ++i) {
         int n = bn * BN + row0 + ROWS_PER_IT * i;
         n = n < p.N ? n : p.N - 1;  // clamp: columns >= N are never stored
-        w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(p.diag ? 0 : n) * p.Kpad + chunk * VEC) * EB;
+        w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(p.diag ? 0 : n) * (p.ldw ? p.ldw : p.Kpad) + chunk * VEC) * EB;
     }
 
     const int ktiles_all = p.Kpad / BKE;

@@ -100,6 +100,7 @@ struct GemmParams {
     int big_tile;         // 1: 256 x 160 block tile (8 waves) instead of 128 x 160
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;
+    int ldw;              // weight row stride in elements (0: Kpad) -- lets a device activation act as the W operand
     int diag;             // timing diagnostic: every tile row reads row 0 (operands served from L1); results are wrong
 };
 
@@ -127,7 +128,9 @@ int launch_gn_coef(const double* partial, const float* gamma, const float* beta,
                    int nchunk, float eps, hipStream_t s);
 int launch_layernorm(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta,
                      int rows, int C, float eps, hipStream_t s);
-int launch_nchw_to_nhwc(const float* in, void* out, int out_dt, int B, int C, int H, int W, int Cpad, hipStream_t s);
+int launch_nchw_to_nhwc(const float* in, void* out, int out_dt, int B, int C, int H, int W, int Cpad, hipStream_t s,
+                        float scale = 1.0f);
+int launch_softmax_rows(const float* in, void* out, int out_dt, int rows, int n, hipStream_t s);
 int launch_nhwc_to_nchw(const void* in, int in_dt, float* out, int B, int C, int H, int W, int Cpad, float scale, hipStream_t s);
 int launch_cast_rows(const float* in, void* out, int out_dt, long long rows, int C, int Cpad, hipStream_t s);
 int launch_concat_add(const void* a, const void* a_add, const void* b, const void* b_add, void* out, int dt,

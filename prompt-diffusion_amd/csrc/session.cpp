@@ -273,7 +273,7 @@ static int check_args(pd_engine* e, const pd_sample_args* a) {
     if (!a->x_T || !a->ctx_cond || !a->pair || !a->query) { pd_set_error("x_T, ctx_cond, pair and query are required"); return 1; }
     if (a->use_cfg && !a->ctx_uncond) { pd_set_error("use_cfg needs ctx_uncond"); return 1; }
     for (auto& p : e->params)
-        if (!p.loaded) { pd_set_error("weights not loaded: '%s' (and possibly more)", p.name.c_str()); return 1; }
+        if (p.group == 0 && !p.loaded) { pd_set_error("weights not loaded: '%s' (and possibly more)", p.name.c_str()); return 1; }
     return 0;
 }
 
@@ -405,7 +405,7 @@ int pd_init_random_weights(pd_engine* e, uint64_t seed) {
 int pd_weights_missing(pd_engine* e) {
     int n = 0;
     if (e)
-        for (auto& p : e->params) n += p.loaded ? 0 : 1;
+        for (auto& p : e->params) n += (p.group == 0 && !p.loaded) ? 1 : 0;
     return n;
 }
 

@@ -39,6 +39,8 @@ class pd_config(C.Structure):
         ("num_heads", C.c_int32), ("context_dim", C.c_int32), ("context_len", C.c_int32),
         ("hint_widths", C.c_int32 * 7), ("timesteps", C.c_int32), ("linear_start", C.c_double),
         ("linear_end", C.c_double), ("precision", C.c_int32), ("stream_f32", C.c_int32),
+        ("vae_ch", C.c_int32), ("vae_num_levels", C.c_int32), ("vae_ch_mult", C.c_int32 * PD_MAX_LEVELS),
+        ("vae_num_res_blocks", C.c_int32), ("vae_out_ch", C.c_int32), ("scale_factor", C.c_double),
         ("reserved", C.c_int32 * 6),
     ]
 
@@ -78,6 +80,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32]
     lib.pd_init_random_weights.argtypes = [C.c_void_p, C.c_uint64]
     lib.pd_weights_missing.argtypes = [C.c_void_p]
+    lib.pd_vae_weights_missing.argtypes = [C.c_void_p]
+    lib.pd_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.pd_eps.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]
     lib.pd_control_shape.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 3
     lib.pd_ddim_sample.argtypes = [C.c_void_p, C.POINTER(pd_sample_args), C.c_int32, C.c_void_p, C.c_void_p]
@@ -111,7 +115,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 EXPORTS = [
     "pd_last_error", "pd_abi_version", "pd_engine_create", "pd_engine_destroy", "pd_param_count", "pd_param_info",
-    "pd_load_weights", "pd_init_random_weights", "pd_weights_missing", "pd_eps", "pd_control_shape", "pd_ddim_sample",
+    "pd_load_weights", "pd_init_random_weights", "pd_weights_missing", "pd_vae_weights_missing", "pd_vae_decode", "pd_eps", "pd_control_shape", "pd_ddim_sample",
     "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_eps_at", "pd_sample_end",
     "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3",
     "pd_profile_read", "pd_profile_dump",
@@ -139,6 +143,11 @@ def make_config(cfg: ModelConfig, precision: int = PD_PREC_BF16, stream_f32: boo
     c.linear_start, c.linear_end = cfg.linear_start, cfg.linear_end
     c.precision = precision
     c.stream_f32 = 1 if stream_f32 else 0
+    c.vae_ch = cfg.vae_ch
+    c.vae_num_levels = len(cfg.vae_ch_mult)
+    for i, m in enumerate(cfg.vae_ch_mult):
+        c.vae_ch_mult[i] = m
+    c.vae_num_res_blocks, c.vae_out_ch, c.scale_factor = cfg.vae_num_res_blocks, cfg.vae_out_ch, cfg.scale_factor
     return c
 
 
@@ -231,6 +240,23 @@ class Engine:
 
     def weights_missing(self) -> int:
         return int(self.lib.pd_weights_missing(self._h))
+
+    def vae_weights_missing(self) -> int:
+        return int(self.lib.pd_vae_weights_missing(self._h))
+
+    def vae_decode(self, latents):
+        """decode_first_stage (ddpm.py:820-828): latents [B,4,h,w] -> images [B,3,8h,8w] in about [-1, 1]."""
+        b = _Buf(latents)
+        B, _, h, w = b.owner.shape
+        if b.mem == PD_MEM_DEVICE:
+            import torch
+            out = torch.empty((B, self.cfg.vae_out_ch, 8 * h, 8 * w), dtype=torch.float32, device=b.owner.device)
+            op = out.data_ptr()
+        else:
+            out = np.empty((B, self.cfg.vae_out_ch, 8 * h, 8 * w), np.float32)
+            op = out.ctypes.data
+        self._check(self.lib.pd_vae_decode(self._h, b.ptr, B, h, w, b.mem, op))
+        return out
 
     # ------------------------------------------------------------------ operator boundary
     def control_shapes(self, h: int, w: int) -> List[Tuple[int, int, int]]:

@@ -10,7 +10,9 @@ CFG order (:1108, :1269-1270).  The denoising loop itself runs in the HIP engine
 Out of the hot path, so injected rather than built here:
   * ``text_encoder(list_of_prompts) -> [B, 77, 768]`` -- without it pass ``prompt_embeds`` /
     ``negative_prompt_embeds`` (the north star consumes the CLIP embedding as a fixed context tensor);
-  * ``vae_decode(latents / scaling_factor) -> images in [-1, 1]`` -- without it use ``output_type="latent"``.
+  * the VAE decoder: built into the engine (``pd_vae_decode``) when the checkpoint's ``first_stage_model.*``
+    tensors are loaded; a ``vae_decode(latents / scaling_factor) -> images in [-1, 1]`` callable overrides it; with
+    neither use ``output_type="latent"``.
 """
 from __future__ import annotations
 
@@ -278,10 +280,13 @@ class PromptDiffusionPipeline:
         if output_type == "latent":
             images = lat
         else:
-            if self.vae_decode is None:
-                raise ValueError('output_type other than "latent" needs a vae_decode callable (SURVEY.md N1: the VAE runs '
-                                 "once after the loop and is not part of the engine)")
-            img = _to_numpy(self.vae_decode(lat / np.float32(self.vae_scaling_factor)))
+            if self.vae_decode is not None:
+                img = _to_numpy(self.vae_decode(lat / np.float32(self.vae_scaling_factor)))
+            elif getattr(self.engine.cfg, "vae_ch", 0) > 0 and self.engine.vae_weights_missing() == 0:
+                img = _to_numpy(self.engine.vae_decode(lat))      # divides by scaling_factor itself (ddpm.py:827)
+            else:
+                raise ValueError('output_type other than "latent" needs first-stage weights in the engine '
+                                 "(first_stage_model.decoder.* / post_quant_conv.*) or a vae_decode callable")
             img = np.clip(img / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)      # denormalize, NHWC
             if output_type == "pil":
                 from PIL import Image

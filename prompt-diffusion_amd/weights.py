@@ -46,6 +46,13 @@ class ModelConfig:
     linear_start: float = 0.00085
     linear_end: float = 0.0120
 
+    # first-stage KL-VAE decoder, models/cldm_v15.yaml:64-85 (vae_ch = 0: not built)
+    vae_ch: int = 128
+    vae_ch_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    vae_num_res_blocks: int = 2
+    vae_out_ch: int = 3
+    scale_factor: float = 0.18215       # cldm_v15.yaml:17
+
     @property
     def time_embed_dim(self) -> int:
         return 4 * self.model_channels
@@ -55,7 +62,7 @@ SD15 = ModelConfig()
 # A reduced network with the same topology (4 levels, attention at ds 1/2/4,
 # 8 heads) used by fast parity tests: channels 64/128/256/256, dh 8/16/32.
 TINY = ModelConfig(model_channels=64, context_dim=96, context_len=77,
-                   hint_widths=(8, 8, 16, 16, 24, 24, 32))
+                   hint_widths=(8, 8, 16, 16, 24, 24, 32), vae_ch=32)
 
 Spec = Tuple[str, Tuple[int, ...], str]  # (name, shape, kind)
 
@@ -218,6 +225,67 @@ def controlnet_spec(cfg: ModelConfig, prefix: str = CNET_PREFIX) -> List[Spec]:
 
 def param_spec(cfg: ModelConfig) -> List[Spec]:
     return unet_spec(cfg) + controlnet_spec(cfg)
+
+
+VAE_PREFIX = "first_stage_model."
+
+
+def vae_layout(cfg: ModelConfig) -> List[dict]:
+    """Decoder.up levels in EXECUTION order (highest i_level first), ldm/modules/diffusionmodules/model.py:588-606."""
+    nres = len(cfg.vae_ch_mult)
+    block_in = cfg.vae_ch * cfg.vae_ch_mult[-1]
+    out = []
+    for i_level in reversed(range(nres)):
+        block_out = cfg.vae_ch * cfg.vae_ch_mult[i_level]
+        blocks = []
+        for _ in range(cfg.vae_num_res_blocks + 1):
+            blocks.append((block_in, block_out))
+            block_in = block_out
+        out.append(dict(level=i_level, blocks=blocks, upsample=i_level != 0, ch=block_in))
+    return out
+
+
+def _vres(prefix: str, cin: int, cout: int) -> Iterator[Spec]:
+    # ResnetBlock (temb_channels = 0), model.py:82-141
+    yield prefix + "norm1.weight", (cin,), "gamma"
+    yield prefix + "norm1.bias", (cin,), "beta"
+    yield from _conv(prefix + "conv1.", cin, cout, 3)
+    yield prefix + "norm2.weight", (cout,), "gamma"
+    yield prefix + "norm2.bias", (cout,), "beta"
+    yield from _conv(prefix + "conv2.", cout, cout, 3)
+    if cin != cout:
+        yield from _conv(prefix + "nin_shortcut.", cin, cout, 1)
+
+
+def vae_spec(cfg: ModelConfig, prefix: str = VAE_PREFIX) -> List[Spec]:
+    """post_quant_conv + Decoder parameters in the reference's registration order
+    (ldm/models/autoencoder.py:34, model.py:546-653): decoder first (conv_in, mid, up.0..3, norm_out, conv_out),
+    then post_quant_conv."""
+    if cfg.vae_ch <= 0:
+        return []
+    d = prefix + "decoder."
+    top = cfg.vae_ch * cfg.vae_ch_mult[-1]
+    out: List[Spec] = list(_conv(d + "conv_in.", cfg.in_channels, top, 3))
+    out += list(_vres(d + "mid.block_1.", top, top))
+    out += [(d + "mid.attn_1.norm.weight", (top,), "gamma"), (d + "mid.attn_1.norm.bias", (top,), "beta")]
+    for n in ("q", "k", "v", "proj_out"):
+        out += list(_conv(d + f"mid.attn_1.{n}.", top, top, 1))
+    out += list(_vres(d + "mid.block_2.", top, top))
+    by_level = {l["level"]: l for l in vae_layout(cfg)}
+    for lvl in range(len(cfg.vae_ch_mult)):          # module order: up.0 .. up.N-1
+        l = by_level[lvl]
+        for j, (ci, co) in enumerate(l["blocks"]):
+            out += list(_vres(d + f"up.{lvl}.block.{j}.", ci, co))
+        if l["upsample"]:
+            out += list(_conv(d + f"up.{lvl}.upsample.conv.", l["ch"], l["ch"], 3))
+    out += [(d + "norm_out.weight", (cfg.vae_ch,), "gamma"), (d + "norm_out.bias", (cfg.vae_ch,), "beta")]
+    out += list(_conv(d + "conv_out.", cfg.vae_ch, cfg.vae_out_ch, 3))
+    out += list(_conv(prefix + "post_quant_conv.", cfg.in_channels, cfg.in_channels, 1))
+    return out
+
+
+def synth_vae_state_dict(cfg: ModelConfig, seed: int = 1234) -> Dict[str, np.ndarray]:
+    return {n: synth_tensor(n, s, k, seed) for n, s, k in vae_spec(cfg)}
 
 
 def num_params(cfg: ModelConfig) -> Tuple[int, int]:

@@ -257,6 +257,35 @@ def run_schedule_cases(cfg, W, out):
     print("[golden] schedule.npz written")
 
 
+def run_vae_cases(W, out):
+    """First-stage decoder: reference Decoder + post_quant_conv with the synthetic recipe."""
+    from ldm.modules.diffusionmodules.model import Decoder
+    res = {}
+    for tag, cfg, B, h in (("tiny", W.TINY, 2, 8), ("sd15", W.SD15, 1, 8)):
+        dec = Decoder(ch=cfg.vae_ch, out_ch=cfg.vae_out_ch, ch_mult=cfg.vae_ch_mult, num_res_blocks=cfg.vae_num_res_blocks,
+                      attn_resolutions=[], dropout=0.0, in_channels=3, resolution=256, z_channels=cfg.in_channels)
+        pq = torch.nn.Conv2d(cfg.in_channels, cfg.in_channels, 1)
+        spec = {n[len(W.VAE_PREFIX):]: (s_, k) for n, s_, k in W.vae_spec(cfg)}
+        dsd = dec.state_dict()
+        assert [("decoder." + k) for k in dsd.keys()] == [k for k in spec.keys() if k.startswith("decoder.")], "decoder inventory mismatch"
+        dec.load_state_dict({k: torch.from_numpy(W.synth_tensor(W.VAE_PREFIX + "decoder." + k, v.shape, spec["decoder." + k][1]))
+                             for k, v in dsd.items()})
+        pq.load_state_dict({k: torch.from_numpy(W.synth_tensor(W.VAE_PREFIX + "post_quant_conv." + k, v.shape,
+                                                               spec["post_quant_conv." + k][1])) for k, v in pq.state_dict().items()})
+        dec.eval()
+        g = np.random.Generator(np.random.Philox(key=[55, len(tag)]))
+        z = g.standard_normal((B, cfg.in_channels, h, h), dtype=np.float32)
+        with torch.no_grad():
+            x = dec(pq(1.0 / cfg.scale_factor * torch.from_numpy(z)))   # ddpm.py:827-828, autoencoder.py:89-92
+        res[tag + "_z"] = z
+        res[tag + "_x"] = t2n(x)
+        if tag == "sd15":
+            res["sd15_spec"] = np.array(json.dumps([[("decoder." + k), list(v.shape)] for k, v in dsd.items()] +
+                                                   [["post_quant_conv." + k, list(v.shape)] for k, v in pq.state_dict().items()]))
+        print(f"[golden] vae_{tag}: out |mean| {np.abs(res[tag + '_x']).mean():.4f}")
+    np.savez_compressed(os.path.join(out, "vae.npz"), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-sd15", action="store_true")
@@ -289,6 +318,8 @@ def main():
         run_schedule_cases(W.SD15, W, out)
     if want("ops"):
         run_op_cases(W.TINY, W, out)
+    if want("vae"):
+        run_vae_cases(W, out)
     if want("tiny"):
         run_net_case("tiny_b2_16x16_s5", W.TINY, W, B=2, h=16, w=16, S=5, cfg_scale=7.5, eta=0.0, out=out)
         run_net_case("tiny_b1_8x24_s4", W.TINY, W, B=1, h=8, w=24, S=4, cfg_scale=9.0, eta=0.0, out=out)

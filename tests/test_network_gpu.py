@@ -54,7 +54,10 @@ def test_param_registry_matches_reference_checkpoint(golden_dir):
     with open(os.path.join(golden_dir, "state_dict_spec_sd15.json")) as f:
         ref = json.load(f)
     want = [(W.UNET_PREFIX + n, tuple(s)) for n, s in ref["unet"]] + [(W.CNET_PREFIX + n, tuple(s)) for n, s in ref["controlnet"]]
-    assert e.param_names() == want
+    names = e.param_names()
+    assert names[:len(want)] == want
+    # the optional first-stage decoder follows, under the checkpoint's first_stage_model.* names
+    assert names[len(want):] == [(n, tuple(s)) for n, s, _ in W.vae_spec(W.SD15)]
     e.close()
 
 
@@ -134,6 +137,21 @@ def test_fused_groupnorm_option_matches(golden_dir):
     eps = e.eps(np.tile(x_in, (rep, 1, 1, 1)), np.tile(t_in, rep), np.tile(ctx, (rep, 1, 1)), np.tile(pair, (rep, 1, 1, 1)),
                 np.tile(qry, (rep, 1, 1, 1)))
     assert relerr(eps[:2], g["eps"]) < 2e-4 and relerr(eps[-2:], g["eps"]) < 2e-4
+    e.close()
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("tag,cfg", [("tiny", W.TINY), ("sd15", W.SD15)])
+def test_vae_decode_matches_reference(golden_dir, prec, tol, tag, cfg):
+    """decode_first_stage through the engine vs the reference Decoder's own output."""
+    g = np.load(os.path.join(golden_dir, "vae.npz"))
+    e = E.Engine(cfg, precision=prec)
+    for n, s_, k in W.vae_spec(cfg):
+        e.load_tensor(n, W.synth_tensor(n, s_, k))
+    assert e.vae_weights_missing() == 0 and e.weights_missing() > 0
+    x = e.vae_decode(g[tag + "_z"])
+    assert x.shape == g[tag + "_x"].shape
+    assert relerr(x, g[tag + "_x"]) < tol
     e.close()
 
 

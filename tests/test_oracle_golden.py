@@ -125,3 +125,18 @@ def test_sd15_config1_first_and_last_step(golden_dir):
                                           int(tr[i]), float(g["cfg_scale"]))
         assert relerr(x_prev, g["x_inter"][i + 1]) < 1e-4, i
         assert relerr(pred, g["pred_x0"][i + 1]) < 1e-4, i
+
+
+@pytest.mark.parametrize("tag,cfg", [("tiny", W.TINY), ("sd15", W.SD15)])
+def test_vae_decoder_matches_reference(golden_dir, tag, cfg):
+    """decode_first_stage = z/scale_factor -> post_quant_conv -> Decoder."""
+    g = np.load(os.path.join(golden_dir, "vae.npz"))
+    sd = W.synth_vae_state_dict(cfg)
+    if tag == "sd15":
+        ref = json.loads(str(g["sd15_spec"]))
+        mine = [[n[len(W.VAE_PREFIX):], list(s)] for n, s, _ in W.vae_spec(cfg)]
+        assert mine == ref
+        assert sum(int(np.prod(s)) for _, s in ref) == 49490199   # 49.5 M, SURVEY N1
+    x = O.vae_decode(sd, cfg, W.vae_layout(cfg), g[tag + "_z"])
+    assert x.shape == g[tag + "_x"].shape
+    assert relerr(x, g[tag + "_x"]) < 5e-5

@@ -109,6 +109,33 @@ def test_pipeline_call_against_oracle(eng, guess, g_end):
                control_guidance_end=g_end, return_dict=False)
     assert isinstance(tup, tuple) and tup[1] is None
     np.testing.assert_allclose(np.asarray(tup[0]), np.asarray(out.images), rtol=0, atol=0)
-    with pytest.raises(ValueError, match="vae_decode"):
+    with pytest.raises(ValueError, match="first-stage weights|vae_decode"):
         pipe(prompt_embeds=inp["ctx_cond"], negative_prompt_embeds=inp["ctx_uncond"], image=inp["query"].transpose(0, 2, 3, 1),
              image_pair=[a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1)], num_inference_steps=S, latents=inp["x_T"])
+
+
+def test_pipeline_decodes_images_with_engine_vae():
+    """output_type="np": loop + first-stage decode inside the engine, against the oracle (f32 mode)."""
+    cfg = W.TINY
+    e = E.Engine(cfg, precision="f32")
+    sd = W.synth_state_dict(cfg)
+    vsd = W.synth_vae_state_dict(cfg)
+    e.load_state_dict({**sd, **vsd})
+    assert e.vae_weights_missing() == 0
+    B, hw, S = 1, 64, 2
+    inp = W.synth_inputs(cfg, B, hw // 8, hw // 8, seed=5, unit_range=True)
+    lay = O.make_layouts(cfg, W)
+    pipe = PromptDiffusionPipeline(e)
+    a, b = inp["pair"][:, :3], inp["pair"][:, 3:]
+    kw = dict(prompt_embeds=inp["ctx_cond"], negative_prompt_embeds=inp["ctx_uncond"], image=inp["query"].transpose(0, 2, 3, 1),
+              image_pair=[a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1)], num_inference_steps=S, guidance_scale=3.0,
+              latents=inp["x_T"])
+    imgs = pipe(output_type="np", **kw).images
+    lat = _oracle_pipeline(cfg, sd, lay, inp["x_T"], inp["ctx_cond"], inp["ctx_uncond"], inp["pair"], inp["query"], S, 3.0, 1.0,
+                           False, 0.0, 1.0)
+    ref = np.clip(O.vae_decode(vsd, cfg, W.vae_layout(cfg), lat) / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)
+    assert imgs.shape == (B, hw, hw, 3)
+    assert float(np.abs(imgs - ref).max()) < 2e-3
+    pil = pipe(output_type="pil", **kw).images
+    assert pil[0].size == (hw, hw)
+    e.close()
