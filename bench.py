@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra fp32-engine-mode measurement")
+    ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=int (experiments)")
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise ControlNet and UNet on one stream in every pass (used for the committed rocprof summary, so\n"
                          "that per-kernel durations are not stretched by the concurrent kernel of the other stream)")
@@ -93,6 +94,9 @@ def main():
     eng.init_random_weights(1234 + rank)
     if args.single_stream:
         eng.set_option("two_streams", 0)
+    for o in args.opt:
+        k, v = o.split("=")
+        eng.set_option(k, int(v))
 
     gen = torch.Generator(device=dev).manual_seed(2023 + rank)
     x_T = torch.randn((B, 4, h, w), generator=gen, device=dev)

@@ -236,7 +236,10 @@ struct Attn2Cfg {
     static constexpr int NCH = DH * 2 / 16;
     static constexpr int KS = (NCH + 3) / 4;
     static constexpr int NTD = (DH + 15) / 16;
-    static constexpr int KROW = KS * 64 + 16;
+    // K rows: 128-byte rows with the GEMM's XOR swizzle when dh fits them (conflict-free ds_read_b128 fragments),
+    // else padded rows
+    static constexpr bool KSWZ = KS == 2;
+    static constexpr int KROW = KSWZ ? 128 : KS * 64 + 16;
     static constexpr int VROW = TK * 2 + 16;
     static constexpr int K_BYTES = TK * KROW, V_BYTES = NTD * 16 * VROW;
     static constexpr int K_SLOTS = TK * NCH;        // valid 16-byte chunks of a K tile
@@ -244,11 +247,28 @@ struct Attn2Cfg {
     static constexpr int K_IT = (K_SLOTS + 255) / 256, V_IT = (V_SLOTS + 255) / 256;
     static constexpr int SMEM = 2 * (K_BYTES + V_BYTES);
     static_assert(K_IT <= 3 && V_IT <= 3, "staging registers cover 3 + 3 pieces");
+    // dh padded up to the MFMA shapes leaves free slots, used to move softmax VALU work onto the matrix pipe:
+    //  SUBM: a free K-dim slot of S^T = K.Q^T holds K'[key][DH] = 1 and Q'[q][DH] = -m_ref[q], so the MFMA
+    //        itself delivers s - m_ref (Q is pre-scaled by scale*log2e): no per-score FMA.  m_ref is a lazily
+    //        updated bf16-representable reference (softmax is shift-invariant; it only has to bound exp2's
+    //        argument), raised -- with one rescale of O -- when a tile exceeds it by more than LAZY_THR.
+    //  ONES: a free row of V^T is all ones, so row DH of O^T = V^T.P^T accumulates sum_k P (rescaled with O).
+    static constexpr bool SUBM = KS * 32 > DH;
+    static constexpr bool ONES = NTD * 16 > DH;
 };
+constexpr float LAZY_THR = 8.0f;   // exp2 arguments stay <= 8: P <= 256 in bf16, fp32 sums far from overflow
+
+// smallest bf16-representable value >= x (x finite)
+__device__ __forceinline__ float bf16_ceil(float x) {
+    unsigned u = __float_as_uint(x);
+    u = x >= 0.f ? (u + 0xFFFFu) & 0xFFFF0000u : u & 0xFFFF0000u;
+    return __uint_as_float(u);
+}
 
 template <int DH>
 __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnParams p) {
     using Cfg = Attn2Cfg<DH>;
+    auto kpos = [](int row, int c) __attribute__((always_inline)) { return Cfg::KSWZ ? (c ^ ((row >> 1) & 7)) : c; };   // chunk slot of K row
     constexpr int NCH = Cfg::NCH, KS = Cfg::KS, NTD = Cfg::NTD, KROW = Cfg::KROW, VROW = Cfg::VROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -272,6 +292,20 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
             const int c = ks * 4 + fq;
             qf[ks][qt] = c < NCH ? *reinterpret_cast<const uint4*>(Qb + (size_t)q * p.ldq * 2 + c * 16) : make_uint4(0, 0, 0, 0);
         }
+    }
+    const float sl2 = p.scale * 1.4426950408889634f;
+    constexpr bool SUBM = Cfg::SUBM, ONES = Cfg::ONES;
+    constexpr int KSM = DH / 32, FQM = (DH % 32) / 8;    // fragment slot of K-dim index DH
+    if constexpr (SUBM) {   // Q <- Q * scale * log2(e): logits leave the MFMA in exp2 units
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                unsigned* w = reinterpret_cast<unsigned*>(&qf[ks][qt]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w[j] = pack2bf(__uint_as_float(w[j] << 16) * sl2, __uint_as_float(w[j] & 0xFFFF0000u) * sl2);
+            }
     }
     // zero the pad chunks / pad rows of both LDS buffers once (they never change)
     for (int i = tid; i < Cfg::SMEM / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
@@ -339,7 +373,7 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
         static_for<Cfg::K_IT>([&](auto I) __attribute__((always_inline)) {
             const int s = tid + 256 * decltype(I)::value;
             const int r = s / NCH, c = s - r * NCH;
-            if (s < Cfg::K_SLOTS) *reinterpret_cast<uint4*>(sK + r * KROW + c * 16) = KR(I);
+            if (s < Cfg::K_SLOTS) *reinterpret_cast<uint4*>(sK + r * KROW + kpos(r, c) * 16) = KR(I);
         });
         static_for<Cfg::V_IT>([&](auto I) __attribute__((always_inline)) {
             const int s = tid + 256 * decltype(I)::value;
@@ -353,10 +387,18 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
     for (int n = 0; n < NTD; ++n) { o[n][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[n][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float mrow[2] = {-INFINITY, -INFINITY};   // running max of the RAW logits (scale > 0)
     float lrow[2] = {0.f, 0.f};
-    const float sl2 = p.scale * 1.4426950408889634f;
+    float mref[2] = {0.f, 0.f};               // SUBM: reference already subtracted by the MFMA (bf16-representable)
 
     load_tile(0);
     __syncthreads();   // zero fill done before the first tile lands on top of it
+    if constexpr (SUBM) {   // K'[key][DH] = 1.0 in both buffers
+        for (int i = tid; i < 2 * TK; i += 256)
+            *reinterpret_cast<unsigned*>(smem + (i / TK) * (Cfg::K_BYTES + Cfg::V_BYTES) + (i % TK) * KROW + kpos(i % TK, NCH) * 16) = 0x3F80u;
+    }
+    if constexpr (ONES) {   // V^T row DH = 1.0 for all 64 keys, both buffers
+        for (int i = tid; i < 2 * (TK / 2); i += 256)
+            *reinterpret_cast<unsigned*>(smem + (i / (TK / 2)) * (Cfg::K_BYTES + Cfg::V_BYTES) + Cfg::K_BYTES + DH * VROW + (i % (TK / 2)) * 4) = 0x3F803F80u;
+    }
     store_tile(0);
     __syncthreads();
 
@@ -364,7 +406,7 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
     for (int t = 0; t < ntiles; ++t) {
         const int t0 = t * TK;
         const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile(t0 + TK);
+        if (t + 1 < ntiles) load_tile(p.legacy == 2 ? 0 : t0 + TK);   // legacy==2: timing diagnostic (tile 0 re-read: L1-hot)
         const char* sK = smem + buf * (Cfg::K_BYTES + Cfg::V_BYTES);
         const char* sV = sK + Cfg::K_BYTES;
 
@@ -375,7 +417,7 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * KROW + (ks * 4 + fq) * 16);
+                const uint4 kf = *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * KROW + kpos(fr, ks * 4 + fq) * 16);
                 mma16<false>(kf, qf[ks][0], s[kt][0]);
                 mma16<false>(kf, qf[ks][1], s[kt][1]);
             }
@@ -387,6 +429,56 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
                 for (int j = 0; j < 4; ++j)
                     if (t0 + kt * 16 + fq * 4 + j >= p.Nk) { s[kt][0][j] = -INFINITY; s[kt][1][j] = -INFINITY; }
         }
+        if constexpr (SUBM) {
+            float mx[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float m = max3f(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+                m = max3f(m, s[0][qt][3], s[1][qt][0]);
+                m = max3f(m, s[1][qt][1], s[1][qt][2]);
+                m = max3f(m, s[1][qt][3], s[2][qt][0]);
+                m = max3f(m, s[2][qt][1], s[2][qt][2]);
+                m = max3f(m, s[2][qt][3], s[3][qt][0]);
+                m = max3f(m, s[3][qt][1], s[3][qt][2]);
+                mx[qt] = fmaxf(m, s[3][qt][3]);
+            }
+            // s already is (logit - m_ref) in exp2 units.  Rare path (always the first tile): move the reference.
+            if (t == 0 || __any(fmaxf(mx[0], mx[1]) > LAZY_THR)) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    float m = mx[qt];
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    const float mnew = (t == 0 || m > 0.f) ? bf16_ceil(mref[qt] + m) : mref[qt];
+                    const float delta = mnew - mref[qt];
+                    mref[qt] = mnew;
+                    if (fq == FQM) qf[KSM][qt].x = __float_as_uint(-mnew) >> 16;   // Q'[q][DH] = -m_ref (Q'[q][DH+1] = 0)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[kt][qt][j] -= delta;
+                    if (t > 0) {
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        if constexpr (!ONES) lrow[qt] *= alpha;
+#pragma unroll
+                        for (int n = 0; n < NTD; ++n) o[n][qt] *= alpha;
+                    }
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float ps = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float e = __builtin_amdgcn_exp2f(s[kt][qt][j]);
+                        s[kt][qt][j] = e;
+                        if constexpr (!ONES) ps += e;
+                    }
+                if constexpr (!ONES) lrow[qt] += ps;
+            }
+        } else {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             float mx = max3f(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
@@ -416,6 +508,7 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
 #pragma unroll
             for (int n = 0; n < NTD; ++n) o[n][qt] *= alpha;
         }
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             uint4 pf[2];
@@ -442,9 +535,14 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
 
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = lrow[qt];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if constexpr (ONES) {   // row DH of O^T: held by the lanes with 4*fq == DH % 16
+            l = __shfl(o[DH / 16][qt][0], ((DH % 16) / 4) * 16 + fr);
+        } else {
+            l = lrow[qt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = 1.0f / l;
         const int q = q0 + qt * 16 + fr;
         if (q >= p.Nq) continue;
@@ -507,7 +605,7 @@ int launch_prec(const AttnParams& p, hipStream_t s) {
 
 int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s) {
     if (p.Nq <= 0 || p.Nk <= 0) return 0;
-    if (!f32mode && !p.legacy) {
+    if (!f32mode && p.legacy != 1) {
         switch (p.dh) {
             case 8: return launch_attn2<8>(p, s);
             case 16: return launch_attn2<16>(p, s);

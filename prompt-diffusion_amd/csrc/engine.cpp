@@ -312,6 +312,8 @@ int pd_engine::build() {
     gn_partial_cap = 8u << 20;
     gn_partial = reinterpret_cast<double*>(dmalloc(gn_partial_cap));
     gn_partial2 = reinterpret_cast<double*>(dmalloc(gn_partial_cap));
+    tile_cnt = reinterpret_cast<int*>(dmalloc(kTileCnt * sizeof(int)));    // dmalloc zero-fills
+    tile_cnt2 = reinterpret_cast<int*>(dmalloc(kTileCnt * sizeof(int)));
     if (hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking) != hipSuccess) stream2 = nullptr;
     if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -555,7 +557,9 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         const int tiles = gemm_tiles(p.M, m.N);
         const int ktiles = m.Kpad / (128 / (int)dt_size(T));
         int splitk = 1;
-        if (!m.geglu && !VT && tiles < opt_splitk_tiles && ktiles >= 16 && m.N % 4 == 0) {
+        // linear layers with a short K and at least half a chip of tiles: one 8-wave block per CU instead of split-K
+        const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
+        if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
             splitk = (512 + tiles - 1) / tiles;
             if (splitk > ktiles / 8) splitk = ktiles / 8;
             if (splitk > 8) splitk = 8;
@@ -566,9 +570,10 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
             if (!arena.dry && arena.top > arena.cap) { splitk = 1; p.slab = nullptr; }  // no room (op hooks outside a session)
         }
         p.splitk = splitk;
+        p.tile_cnt = (splitk > 1 && opt_splitk_fused) ? tile_cnt : nullptr;
         // 256-row tiles when they still give every CU a block (1 block of 8 waves per CU)
         p.big_tile = (opt_bigtile && splitk == 1 && ((p.M + 255) / 256) * ((m.N + 159) / 160) >= 256) ? 1 : 0;
-        if (opt_dense_k > 0 && ktiles <= opt_dense_k && m.taps == 1) p.big_tile = 2;
+        if (dense8 && tiles < opt_splitk_tiles) p.big_tile = 2;
         // 256 x 320 tiles for linear layers that still give (almost) every CU a block
         {
             const int t3 = ((p.M + 255) / 256) * ((m.N + 319) / 320);
@@ -691,7 +696,7 @@ int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const v
     p.Nq = Nq; p.Nk = Nk; p.heads = cfg.num_heads; p.dh = C / cfg.num_heads;
     p.scale = (float)(1.0 / std::sqrt((double)p.dh));
     p.B = B;
-    p.legacy = opt_attn_legacy ? 1 : 0;
+    p.legacy = opt_attn_legacy ? 1 : (opt_diag == 2 ? 2 : 0);
     ++launches;
     ProfRec rec{};
     if (profiling) {
@@ -873,6 +878,7 @@ void pd_engine::swap_context() {
     std::swap(arena, arena2);
     std::swap(stream, stream2);
     std::swap(gn_partial, gn_partial2);
+    std::swap(tile_cnt, tile_cnt2);
 }
 
 // Called by the UNet right before its decoder: wait for the ControlNet stream, then apply the guess-mode zeroing.

@@ -201,6 +201,7 @@ struct pd_engine {
     Arena arena2;
     hipStream_t stream2 = nullptr;
     double* gn_partial2 = nullptr;
+    int* tile_cnt2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool cn_pending = false;
     bool opt_two_streams = true;
@@ -208,11 +209,13 @@ struct pd_engine {
     int join_controlnet();
     Session ses;
     int verbose = 0;
+    bool opt_splitk_fused = false; // split-K sums + epilogue run in the last-arriving slice instead of a finalize kernel
     int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
     int opt_diag = 0;          // timing diagnostic (wrong results): GEMM operands all read row 0
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
-    int opt_dense_k = 0;       // linear layers with at most this many K steps use the 16-waves-per-CU tile shape
+    int opt_dense_tiles = 128;
+    int opt_dense_k = 40;      // linear layers with at most this many K steps and >= opt_dense_tiles tiles: one 8-wave block per CU, no split-K
     bool opt_bigtile = true;  // 256-row GEMM tiles where the grid still fills the chip
     // apply GroupNorm(+SiLU) inside the patch conv's staging.  Measured neutral-to-negative in round 1 (the SiLU VALU work
     // lands on the MFMA waves and the halo is transformed 1.27x redundantly), so it is off by default.
@@ -229,6 +232,8 @@ struct pd_engine {
     void prof_begin(ProfRec& r, int klass, double flops);
     void prof_end(ProfRec& r);
     double* gn_partial = nullptr;  // scratch for GroupNorm partial sums
+    int* tile_cnt = nullptr;       // split-K arrival counters (kTileCnt ints, zero between GEMMs), one set per stream
+    static constexpr int kTileCnt = 4096;
     size_t gn_partial_cap = 0;
 
     // construction

@@ -18,7 +18,8 @@
 // fp32 -> 4 x v_mfma_f32_16x16x4_f32 on the same 16-byte fragment (k order permuted identically on
 // both operands, which leaves the dot product unchanged).
 // Small-M layers (the 8x8 and 16x16 levels) split K across blockIdx.y: each slice writes an fp32 slab
-// with plain stores and splitk_finalize_kernel sums the slabs in slice order (deterministic) and applies
+// with plain stores; the slice arriving last at the tile's counter (or, without counters,
+// splitk_finalize_kernel) sums the slabs in slice order (deterministic) and applies
 // the epilogue.
 #include "pd_common.h"
 #include "pd_mma.h"
@@ -271,19 +272,69 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
 
     // ---- epilogue: lane holds channels n..n+3 (rows of the swapped MFMA) of pixel m
     if (p.splitk > 1) {
-        float* slab = reinterpret_cast<float*>(p.slab) + (size_t)kslice * p.M * p.N;
+        if (!p.tile_cnt) {   // plain slab stores; splitk_finalize_kernel sums them after this launch
+            float* slab = reinterpret_cast<float*>(p.slab) + (size_t)kslice * p.M * p.N;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int gm = bm * BM + wm * WTM + m * 16 + fr;
-            if (gm >= p.M) continue;
+            for (int m = 0; m < MT; ++m) {
+                const int gm = bm * BM + wm * WTM + m * 16 + fr;
+                if (gm >= p.M) continue;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
-                if (gn >= p.N) continue;
-                *reinterpret_cast<f32x4*>(slab + (size_t)gm * p.N + gn) = acc[n][m];
+                for (int n = 0; n < NT; ++n) {
+                    const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
+                    if (gn >= p.N) continue;
+                    *reinterpret_cast<f32x4*>(slab + (size_t)gm * p.N + gn) = acc[n][m];
+                }
             }
+            return;
         }
-        return;
+        // Fused finalize: the slice that arrives last at this tile's counter sums all slabs in slice order
+        // (bit-identical to splitk_finalize_kernel, independent of arrival order) and runs the epilogue.
+        // Cross-XCD visibility without L2 flushes: every slab byte is stored write-through (sc1) and every
+        // slab load is an sc1 load; the counter is a relaxed agent-scope atomic.  The "last" flag travels
+        // through the staging LDS (free after the K loop's closing barrier).
+        if constexpr (BM == 128 && WM == 2 && WN == 2) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)((size_t)p.splitk * p.M * p.N * 4), 0x00020000);
+            constexpr int SC1 = 16;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gm = bm * BM + wm * WTM + m * 16 + fr;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
+                    if (gm >= p.M || gn >= p.N) continue;
+                    const unsigned off = (unsigned)(((kslice * p.M + gm) * p.N + gn) * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[n][m]), rs, off, 0, SC1);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
+            __syncthreads();
+            int* s_last = reinterpret_cast<int*>(smem);
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(p.tile_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == p.splitk - 1;
+                if (last) __hip_atomic_store(p.tile_cnt + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next GEMM
+                *s_last = last;
+            }
+            __syncthreads();
+            if (!*s_last) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: keep the slab loads below the counter
+            for (int s = 0; s < p.splitk; ++s) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int gm = bm * BM + wm * WTM + m * 16 + fr;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
+                        if (gm >= p.M || gn >= p.N) continue;
+                        const unsigned off = (unsigned)(((s * p.M + gm) * p.N + gn) * 4);
+                        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, SC1));
+                        acc[n][m] = s == 0 ? t : acc[n][m] + t;
+                    }
+                }
+            }
+        } else {
+            return;
+        }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -356,7 +407,7 @@ int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, s, p);
     if (hipGetLastError() != hipSuccess) return 1;
     if (mid) (void)hipEventRecord(mid, s);   // profiling: end of the contraction kernel proper
-    if (p.splitk > 1) {
+    if (p.splitk > 1 && !p.tile_cnt) {
         long long total = (long long)p.M * (p.N / 4);
         int nb = (int)((total + 255) / 256);
         if (nb > 4096) nb = 4096;

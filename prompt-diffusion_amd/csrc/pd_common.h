@@ -8,6 +8,7 @@ enum PdDType : int { DT_F32 = 0, DT_BF16 = 1 };
 static inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 #if defined(__HIPCC__)
@@ -97,6 +98,7 @@ struct GemmParams {
     int Nout;             // GEGLU: logical output columns (N/2 rounded), else == N
     int splitk;           // >1: grid.y slices K; each slice stores an fp32 slab, a finalize pass sums them + epilogue
     void* slab;           // [splitk][M][N] fp32 workspace
+    int* tile_cnt;        // split-K: one zeroed counter per 128x160 tile -> finalize fused into the last-arriving slice; null: separate pass
     int big_tile;         // 1: 256 x 160 block tile (8 waves) instead of 128 x 160
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;

@@ -584,12 +584,14 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!e || !key) { pd_set_error("null argument"); return 1; }
     if (!strcmp(key, "verbose")) { e->verbose = (int)value; return 0; }
     if (!strcmp(key, "conv_patch")) { e->opt_patch = value != 0; return 0; }
+    if (!strcmp(key, "splitk_fused")) { e->opt_splitk_fused = value != 0; return 0; }
     if (!strcmp(key, "splitk_tiles")) { e->opt_splitk_tiles = (int)value; return 0; }
     if (!strcmp(key, "attn_legacy")) { e->opt_attn_legacy = value != 0; return 0; }
     if (!strcmp(key, "gn_fuse")) { e->opt_gn_fuse = value != 0; return 0; }
     if (!strcmp(key, "two_streams")) { e->opt_two_streams = value != 0; return 0; }
     if (!strcmp(key, "diag")) { e->opt_diag = (int)value; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
+    if (!strcmp(key, "dense_tiles")) { e->opt_dense_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_k")) { e->opt_dense_k = (int)value; return 0; }
     if (!strcmp(key, "big_tile")) { e->opt_bigtile = value != 0; return 0; }
     if (!strcmp(key, "profile")) {

@@ -66,6 +66,31 @@ def test_conv2d_epilogues(eng):
     assert relerr(eng.op_conv2d(x, w, b, scale=0.825, residual=r, stream_out=True), ref * 0.825 + r) < TOL[eng.prec]
 
 
+def test_splitk_fused_finalize_is_bit_identical(eng):
+    """Split-K layers (small M, long K): the slabs are summed in slice order either by the slice that arrives
+    last at the tile counter (default) or by splitk_finalize_kernel (option splitk_fused=0).  Both orders are
+    fixed, so the results must be bit-identical, run after run (the counters reset themselves)."""
+    g = rng(11)
+    x = g.standard_normal((3, 320, 16, 16), dtype=np.float32)
+    w = (g.standard_normal((320, 320, 3, 3), dtype=np.float32) / 54).astype(np.float32)
+    b = g.standard_normal(320, dtype=np.float32) * 0.1
+    r = g.standard_normal((3, 320, 16, 16), dtype=np.float32)
+    xl = g.standard_normal((1024, 2560), dtype=np.float32)
+    wl = (g.standard_normal((1288, 2560), dtype=np.float32) / 50).astype(np.float32)
+    try:
+        eng.set_option("splitk_fused", 0)
+        c0 = eng.op_conv2d(x, w, b, scale=0.5, residual=r, stream_out=True)
+        l0 = eng.op_linear(xl, wl, None)
+        eng.set_option("splitk_fused", 1)
+        for _ in range(3):
+            assert np.array_equal(eng.op_conv2d(x, w, b, scale=0.5, residual=r, stream_out=True), c0)
+            assert np.array_equal(eng.op_linear(xl, wl, None), l0)
+    finally:
+        eng.set_option("splitk_fused", 1)
+    assert relerr(c0, O.conv2d(x, w, b) * 0.5 + r) < TOL[eng.prec]
+    assert relerr(l0, O.linear(xl, wl)) < TOL[eng.prec]
+
+
 @pytest.mark.parametrize("M,K,N", [(300, 64, 256), (7, 1280, 320), (128, 320, 960), (77, 96, 512), (1, 320, 1280)])
 def test_linear(eng, M, K, N):
     g = rng(3)
