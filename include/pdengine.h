@@ -180,6 +180,9 @@ int pd_profile_dump(pd_engine* e, const char* csv_path); /* one row per profiled
 int pd_bench_conv3x3(pd_engine* e, int32_t Bf, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      int32_t iters, float* ms);
 
+/* Same for one Linear / conv1x1 layer ([M,K] x [N,K]^T, optional residual add) in isolation. */
+int pd_bench_linear(pd_engine* e, int32_t M, int32_t K, int32_t N, int32_t residual, int32_t iters, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

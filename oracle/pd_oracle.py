@@ -407,3 +407,52 @@ def vae_decode(sd, cfg, vae_layout, z):
             h = conv2d(h, p(f"decoder.up.{lvl['level']}.upsample.conv.weight"), p(f"decoder.up.{lvl['level']}.upsample.conv.bias"))
     h = silu(group_norm(h, p("decoder.norm_out.weight"), p("decoder.norm_out.bias"), eps=1e-6))
     return conv2d(h, p("decoder.conv_out.weight"), p("decoder.conv_out.bias"))
+
+
+# ---------------------------------------------------------------------------------------------------
+# UniPC.  The reference takes this scheduler from diffusers (`README.md:49`), which is not in
+# the reference tree: PARITY UNPINNED.  Independent fp64 restatement of the published algorithm (Zhao et al. 2023,
+# UniP-2 / UniC-2, data prediction, B(h) = e^h - 1) with the order <= 2 coefficients written out in closed form --
+# deliberately not the generic R/b solve the product scheduler uses, so that the two can check each other.
+def unipc2_sample(eps_fn, x_T, alphas_cumprod, timesteps):
+    """eps_fn(x, t) -> eps.  timesteps descending; an extra final point with sigma = 0 is appended.
+    Order warm-up 1, 2, 2, ...; the last step is first order (lower_order_final)."""
+    ac = np.asarray(alphas_cumprod, np.float64)[np.asarray(timesteps, np.int64)]
+    alpha = np.concatenate([np.sqrt(ac), [1.0]])
+    sigma = np.concatenate([np.sqrt(1.0 - ac), [0.0]])
+    with np.errstate(divide="ignore"):
+        lam = np.log(alpha) - np.log(sigma)
+    n = len(timesteps)
+    x = np.asarray(x_T, np.float64)
+    m_prev = None        # x0 prediction at point i-1
+    x_last = None        # sample the predictor started from at point i-1
+    prev_order = 1
+    for i in range(n):
+        m = (x - sigma[i] * np.asarray(eps_fn(x, int(timesteps[i])), np.float64)) / alpha[i]
+        if i > 0:        # UniC: redo the step (i-1 -> i) with the new evaluation at i
+            h = lam[i] - lam[i - 1]
+            phi1 = np.expm1(-h)
+            base = sigma[i] / sigma[i - 1] * x_last - alpha[i] * phi1 * m_prev
+            if prev_order == 1:
+                x = base - alpha[i] * phi1 * 0.5 * (m - m_prev)
+            else:
+                r = (lam[i - 2] - lam[i - 1]) / h
+                b1 = (phi1 / (-h) - 1.0) / phi1
+                b2 = ((phi1 / (-h) - 1.0) / (-h) - 0.5) * 2.0 / phi1
+                rho1 = (b1 - b2) / (1.0 - r)
+                rho2 = b1 - rho1
+                x = base - alpha[i] * phi1 * (rho1 * (m_pp - m_prev) / r + rho2 * (m - m_prev))
+        order = 1 if (i == 0 or i == n - 1) else 2
+        x_last = x
+        if i == n - 1:
+            x_next = m * 1.0                       # sigma -> 0: the data prediction itself
+        else:
+            h = lam[i + 1] - lam[i]
+            phi1 = np.expm1(-h)
+            x_next = sigma[i + 1] / sigma[i] * x - alpha[i + 1] * phi1 * m
+            if order == 2:
+                r = (lam[i - 1] - lam[i]) / h
+                x_next = x_next - alpha[i + 1] * phi1 * 0.5 * (m_prev - m) / r
+        m_pp, m_prev, prev_order = m_prev, m, order
+        x = x_next
+    return x

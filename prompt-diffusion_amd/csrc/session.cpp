@@ -691,4 +691,47 @@ int pd_bench_conv3x3(pd_engine* e, int32_t Bf, int32_t H, int32_t W, int32_t Cin
     return r;
 }
 
+int pd_bench_linear(pd_engine* e, int32_t M, int32_t K, int32_t N, int32_t residual, int32_t iters, float* ms) {
+    if (!e || !ms || iters < 1 || M < 1 || K < 8 || N < 4) { pd_set_error("bad argument"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    WMat m;
+    const size_t owned0 = e->owned.size();
+    e->make_mat(m, N, K, 1, K, true);
+    if (!m.w || !m.bias) { pd_set_error("allocation failed"); return 1; }
+    const size_t eb = dt_size(e->T);
+    void *in = nullptr, *out = nullptr, *res = nullptr;
+    HIP_OK(hipMalloc(&in, (size_t)M * m.cin_pad * eb));
+    HIP_OK(hipMalloc(&out, (size_t)M * N * eb));
+    if (residual) HIP_OK(hipMalloc(&res, (size_t)M * N * eb));
+    launch_fill_random(in, e->T, (long long)M * m.cin_pad, 1.f, 0.f, 1, e->stream);
+    if (res) launch_fill_random(res, e->T, (long long)M * N, 1.f, 0.f, 3, e->stream);
+    launch_fill_random(m.w, e->T, (long long)m.N * m.Kpad, 1.0f / std::sqrt((float)K), 0.f, 2, e->stream);
+    Act a, o, rr;
+    a.p = in; a.B = 1; a.H = M; a.W = 1; a.C = m.cin_pad; a.dt = e->T;
+    o.p = out; o.B = 1; o.H = M; o.W = 1; o.C = N; o.dt = e->T;
+    rr = o; rr.p = res;
+    int r = 0;
+    for (int i = 0; i < 3 && !r; ++i) r = e->gemm(m, a, o, 1, 0, 0, 1.f, res ? &rr : nullptr, nullptr, 0, false, nullptr, 0, 0);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, e->stream));
+    for (int i = 0; i < iters && !r; ++i) r = e->gemm(m, a, o, 1, 0, 0, 1.f, res ? &rr : nullptr, nullptr, 0, false, nullptr, 0, 0);
+    HIP_OK(hipEventRecord(e1, e->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_OK(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / (float)iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(in);
+    hipFree(out);
+    if (res) hipFree(res);
+    while (e->owned.size() > owned0) {
+        hipFree(e->owned.back());
+        e->owned.pop_back();
+    }
+    return r;
+}
+
 }  // extern "C"

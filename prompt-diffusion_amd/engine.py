@@ -99,6 +99,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_get_stat.argtypes = [C.c_void_p, C.c_char_p]
     lib.pd_get_stat.restype = C.c_int64
     lib.pd_bench_conv3x3.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float)]
+    lib.pd_bench_linear.argtypes = [C.c_void_p] + [C.c_int32] * 5 + [C.POINTER(C.c_float)]
     lib.pd_profile_dump.argtypes = [C.c_void_p, C.c_char_p]
     lib.pd_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     # per-op parity hooks (include/pdengine_ops.h)
@@ -117,7 +118,7 @@ EXPORTS = [
     "pd_last_error", "pd_abi_version", "pd_engine_create", "pd_engine_destroy", "pd_param_count", "pd_param_info",
     "pd_load_weights", "pd_init_random_weights", "pd_weights_missing", "pd_vae_weights_missing", "pd_vae_decode", "pd_eps", "pd_control_shape", "pd_ddim_sample",
     "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_eps_at", "pd_sample_end",
-    "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3",
+    "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear",
     "pd_profile_read", "pd_profile_dump",
     "pd_op_conv2d", "pd_op_linear", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention",
 ]
@@ -423,6 +424,11 @@ class Engine:
     def bench_conv3x3(self, Bf: int, H: int, W: int, Cin: int, Cout: int, iters: int = 20) -> float:
         ms = C.c_float()
         self._check(self.lib.pd_bench_conv3x3(self._h, Bf, H, W, Cin, Cout, iters, C.byref(ms)))
+        return float(ms.value)
+
+    def bench_linear(self, M: int, K: int, N: int, residual: bool = False, iters: int = 20) -> float:
+        ms = C.c_float()
+        self._check(self.lib.pd_bench_linear(self._h, M, K, N, 1 if residual else 0, iters, C.byref(ms)))
         return float(ms.value)
 
     # ------------------------------------------------------------------ per-op parity hooks

@@ -258,7 +258,11 @@ class PromptDiffusionPipeline:
         # 6. latents
         x_T = self.prepare_latents(B, self.engine.cfg.in_channels, height, width, generator, latents)
         # 7.2 controlnet_keep gating and per-step scales (pipeline :1196-1202, :1229-1235; controlnet :371-378)
-        n_steps = self.engine.num_ddim_steps(num_inference_steps)
+        if self.scheduler is not None:      # plug-in scheduler: its own time grid (pipeline :1164-1165)
+            self.scheduler.set_timesteps(num_inference_steps)
+            n_steps = len(self.scheduler.timesteps)
+        else:
+            n_steps = self.engine.num_ddim_steps(num_inference_steps)
         keep = [1.0 - float(i / n_steps < control_guidance_start[0] or (i + 1) / n_steps > control_guidance_end[0])
                 for i in range(n_steps)]
         n_ctl = E.PD_NUM_CONTROL
@@ -266,7 +270,8 @@ class PromptDiffusionPipeline:
         scales_step = np.stack([base * np.float32(controlnet_conditioning_scale) * np.float32(k) for k in keep])
         noise = None
         if eta > 0.0:
-            noise = self._randn((n_steps,) + x_T.shape, generator if not isinstance(generator, list) else None)
+            if self.scheduler is None:   # a plug-in scheduler draws its own noise (`generator` is forwarded to step())
+                noise = self._randn((n_steps,) + x_T.shape, generator if not isinstance(generator, list) else None)
         kw = dict(x_T=x_T, ctx_cond=pe, ctx_uncond=ne, pair=pair, query=query, steps=num_inference_steps,
                   cfg_scale=float(guidance_scale), eta=float(eta), use_cfg=do_cfg, guess_mode=guess_mode,
                   control_scales_step=scales_step, noise=noise)
@@ -300,11 +305,13 @@ class PromptDiffusionPipeline:
     # ------------------------------------------------------------------ per-step driver (callbacks / plug-in schedulers)
     def _stepwise(self, kw, scales_step, cb_end, cb_inputs, cb_legacy, cb_steps, pe, ne, eta, generator):
         eng = self.engine
-        n = eng.sample_begin(**kw)
         sched = self.scheduler
+        if sched is not None:       # the engine only evaluates eps at the scheduler's timesteps: no DDIM tables needed
+            kw = {k: v for k, v in kw.items() if k not in ("control_scales_step", "noise")}
+            kw["eta"] = 0.0
+        n = eng.sample_begin(**kw)
         if sched is not None:
-            sched.set_timesteps(kw["steps"])
-            ts = [int(t) for t in sched.timesteps]
+            ts = [int(t) for t in sched.timesteps]       # set_timesteps ran in __call__
             extra = {}
             params = set(inspect.signature(sched.step).parameters.keys())
             if "eta" in params:

@@ -139,3 +139,37 @@ def test_pipeline_decodes_images_with_engine_vae():
     pil = pipe(output_type="pil", **kw).images
     assert pil[0].size == (hw, hw)
     e.close()
+
+
+def test_pipeline_with_unipc_scheduler_against_oracle_replay(eng):
+    """Scheduler plug-in path (README.md:49 swaps in UniPC): the engine evaluates eps at the scheduler's own timesteps
+    (pd_sample_eps_at) and the host scheduler advances the latents.  Replayed with the oracle network and the oracle's
+    independent closed-form UniPC (parity with diffusers itself is unpinned, see schedulers.py); the control window
+    is counted on the scheduler's grid (pipeline_prompt_diffusion.py:1196-1202)."""
+    from prompt_diffusion_amd.schedulers import UniPCMultistepScheduler
+    cfg = W.TINY
+    B, hw, S, gs, scale, g_end = 1, 64, 5, 4.0, 0.9, 0.8
+    inp = W.synth_inputs(cfg, B, hw // 8, hw // 8, seed=21, unit_range=True)
+    sd = W.synth_state_dict(cfg)
+    lay = O.make_layouts(cfg, W)
+    sched = UniPCMultistepScheduler()
+    pipe = PromptDiffusionPipeline(eng, scheduler=sched)
+    a, b = inp["pair"][:, :3], inp["pair"][:, 3:]
+    out = pipe(prompt_embeds=inp["ctx_cond"], negative_prompt_embeds=inp["ctx_uncond"], image=inp["query"].transpose(0, 2, 3, 1),
+               image_pair=[a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1)], num_inference_steps=S, guidance_scale=gs,
+               latents=inp["x_T"], output_type="latent", controlnet_conditioning_scale=scale, control_guidance_end=g_end).images
+    ts = [int(t) for t in sched.timesteps]
+    assert len(ts) == S and ts[0] == 999
+    keep = {t: 1.0 - float((i + 1) / S > g_end) for i, t in enumerate(ts)}
+    pe, ne, pair, query = inp["ctx_cond"], inp["ctx_uncond"], inp["pair"], inp["query"]
+
+    def eps_fn(x, t):
+        x = x.astype(np.float32)
+        x_in = np.concatenate([x, x]); t_in = np.full((2 * B,), t, np.int64)
+        ctx = np.concatenate([ne, pe]); pr = np.concatenate([pair, pair]); qr = np.concatenate([query, query])
+        ctl = [c * np.float32(scale * keep[t]) for c in O.controlnet_forward(sd, cfg, lay, x_in, t_in, pr, qr, ctx)]
+        eps = O.controlled_unet_forward(sd, cfg, lay, x_in, t_in, ctx, ctl)
+        return eps[:B] + np.float32(gs) * (eps[B:] - eps[:B])
+
+    ref = O.unipc2_sample(eps_fn, inp["x_T"], sched.alphas_cumprod, ts)
+    assert relerr(out, ref) < 5e-4
