@@ -167,7 +167,7 @@ int pd_make_schedule(pd_engine* e, int32_t steps, float eta, int64_t* timesteps,
 int pd_synchronize(pd_engine* e);
 void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches on */
 int pd_set_option(pd_engine* e, const char* key, int64_t value); /* "use_graph", "verbose" ... */
-int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches_per_step" */
+int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches", "steps", "gemm8_launches" */
 /* Per-launch timing: while option "profile" is 1 the engine brackets every contraction launch with HIP
  * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel on a conv1x1/linear,
  * 2 = attention, 3 = conv3x3_patch_kernel, -1 = all.  One bracket = one launch (split-K finalize excluded).

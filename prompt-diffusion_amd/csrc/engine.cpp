@@ -545,6 +545,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.gn_coef = gn_coef;
     p.gn_silu = gn_silu ? 1 : 0;
     p.diag = opt_diag;
+    p.persist = opt_persist ? 1 : 0;
     // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
     const bool use_patch = opt_patch && conv_patch_tiles(p, f32) >= 192;
     if (gn_coef && !use_patch) {
@@ -557,9 +558,12 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         const int tiles = gemm_tiles(p.M, m.N);
         const int ktiles = m.Kpad / (128 / (int)dt_size(T));
         int splitk = 1;
+        // big linear layers: 256 x 256 LDS-DMA tile (gemm8.hip) when it still gives every CU a block
+        const bool use8 = opt_gemm8 && !f32 && gemm8_eligible(p) &&
+                          ((p.M + 255) / 256) * ((m.N + 255) / 256) >= opt_gemm8_tiles;
         // linear layers with a short K and at least half a chip of tiles: one 8-wave block per CU instead of split-K
-        const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
-        if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
+        const bool dense8 = !use8 && opt_dense_k > 0 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
+        if (!use8 && !dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
             splitk = (512 + tiles - 1) / tiles;
             if (splitk > ktiles / 8) splitk = ktiles / 8;
             if (splitk > 8) splitk = 8;
@@ -580,6 +584,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
             const int rounds = (t3 + 255) / 256;
             if (opt_wide && splitk == 1 && m.taps == 1 && in.dt == T && t3 >= 256 && t3 * 100 >= rounds * 256 * 85) p.big_tile = 3;
         }
+        if (use8) p.big_tile = 4;
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
     }
     if (arena.dry) return 0;
@@ -596,9 +601,11 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.taps * 10 + p.stride + (p.ups ? 5 : 0);
     }
     hipEvent_t mid = nullptr;
-    if (profiling && !use_patch) { mid = next_event(); rec.klass = m.taps == 9 ? 0 : 1; }
+    const bool use8 = !use_patch && p.big_tile == 4;
+    if (use8) ++gemm8_launches;
+    if (profiling && !use_patch && !use8) { mid = next_event(); rec.klass = m.taps == 9 ? 0 : 1; }
     if (profiling && use_patch) rec.klass = 3;
-    if (use_patch ? launch_conv_patch(p, f32, stream) : launch_gemm(p, f32, stream, mid)) {
+    if (use_patch ? launch_conv_patch(p, f32, stream) : use8 ? launch_gemm8(p, stream) : launch_gemm(p, f32, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;
     }

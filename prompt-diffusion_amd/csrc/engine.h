@@ -215,6 +215,10 @@ struct pd_engine {
     int opt_diag = 0;          // timing diagnostic (wrong results): GEMM operands all read row 0
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
     int opt_dense_tiles = 128;
+    bool opt_persist = true;   // igemm_kernel: persistent tile loop with cross-tile prefetch
+    bool opt_gemm8 = false;    // 256 x 256 LDS-DMA tile kernel for big bf16 linear layers
+    int opt_gemm8_tiles = 256;
+    long long gemm8_launches = 0;
     int opt_dense_k = 40;      // linear layers with at most this many K steps and >= opt_dense_tiles tiles: one 8-wave block per CU, no split-K
     bool opt_bigtile = true;  // 256-row GEMM tiles where the grid still fills the chip
     // apply GroupNorm(+SiLU) inside the patch conv's staging.  Measured neutral-to-negative in round 1 (the SiLU VALU work

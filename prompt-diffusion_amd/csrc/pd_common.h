@@ -103,6 +103,7 @@ struct GemmParams {
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;
     int ldw;              // weight row stride in elements (0: Kpad) -- lets a device activation act as the W operand
+    int persist;          // igemm_kernel: launch one block per resident slot and walk the tiles (cross-tile prefetch)
     int diag;             // timing diagnostic: every tile row reads row 0 (operands served from L1); results are wrong
 };
 
@@ -122,6 +123,8 @@ int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid
 int gemm_tiles(int M, int N);
 int conv_patch_tiles(const GemmParams& p, bool f32mode);  // 0: shape not eligible for the LDS-patch conv kernel
 int launch_conv_patch(const GemmParams& p, bool f32mode, hipStream_t s);
+bool gemm8_eligible(const GemmParams& p);          // gemm8.hip: 256 x 256 LDS-DMA tile, bf16 linear layers
+int launch_gemm8(const GemmParams& p, hipStream_t s);
 int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s);
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,

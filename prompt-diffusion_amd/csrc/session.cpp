@@ -591,6 +591,9 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "two_streams")) { e->opt_two_streams = value != 0; return 0; }
     if (!strcmp(key, "diag")) { e->opt_diag = (int)value; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
+    if (!strcmp(key, "persist")) { e->opt_persist = value != 0; return 0; }
+    if (!strcmp(key, "gemm8")) { e->opt_gemm8 = value != 0; return 0; }
+    if (!strcmp(key, "gemm8_tiles")) { e->opt_gemm8_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_tiles")) { e->opt_dense_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_k")) { e->opt_dense_k = (int)value; return 0; }
     if (!strcmp(key, "big_tile")) { e->opt_bigtile = value != 0; return 0; }
@@ -611,6 +614,7 @@ int64_t pd_get_stat(pd_engine* e, const char* key) {
     if (!strcmp(key, "weight_bytes")) return (int64_t)e->weight_bytes;
     if (!strcmp(key, "launches")) return (int64_t)e->launches;
     if (!strcmp(key, "steps")) return (int64_t)e->ses.S;
+    if (!strcmp(key, "gemm8_launches")) return (int64_t)e->gemm8_launches;
     return -1;
 }
 
@@ -696,8 +700,11 @@ int pd_bench_linear(pd_engine* e, int32_t M, int32_t K, int32_t N, int32_t resid
     HIP_OK(hipSetDevice(e->device));
     WMat m;
     const size_t owned0 = e->owned.size();
-    e->make_mat(m, N, K, 1, K, true);
+    const bool geglu = (residual & 2) != 0;     // bit 1: N counts the 2x-wide GEGLU projection (output N/2 columns)
+    residual &= 1;
+    e->make_mat(m, N, K, 1, K, true, geglu);
     if (!m.w || !m.bias) { pd_set_error("allocation failed"); return 1; }
+    if (geglu) N = m.Nout;
     const size_t eb = dt_size(e->T);
     void *in = nullptr, *out = nullptr, *res = nullptr;
     HIP_OK(hipMalloc(&in, (size_t)M * m.cin_pad * eb));
