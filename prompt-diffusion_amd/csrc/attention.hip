@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
     for (int t = 0; t < ntiles; ++t) {
         const int t0 = t * TK;
         const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile(p.legacy == 2 ? 0 : t0 + TK);   // legacy==2: timing diagnostic (tile 0 re-read: L1-hot)
+        if (t + 1 < ntiles) load_tile(t0 + TK);
         const char* sK = smem + buf * (Cfg::K_BYTES + Cfg::V_BYTES);
         const char* sV = sK + Cfg::K_BYTES;
 
@@ -605,7 +605,7 @@ int launch_prec(const AttnParams& p, hipStream_t s) {
 
 int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s) {
     if (p.Nq <= 0 || p.Nk <= 0) return 0;
-    if (!f32mode && p.legacy != 1) {
+    if (!f32mode && !p.legacy) {
         switch (p.dh) {
             case 8: return launch_attn2<8>(p, s);
             case 16: return launch_attn2<16>(p, s);

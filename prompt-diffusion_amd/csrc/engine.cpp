@@ -703,7 +703,7 @@ int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const v
     p.Nq = Nq; p.Nk = Nk; p.heads = cfg.num_heads; p.dh = C / cfg.num_heads;
     p.scale = (float)(1.0 / std::sqrt((double)p.dh));
     p.B = B;
-    p.legacy = opt_attn_legacy ? 1 : (opt_diag == 2 ? 2 : 0);
+    p.legacy = opt_attn_legacy ? 1 : 0;
     ++launches;
     ProfRec rec{};
     if (profiling) {
