@@ -333,9 +333,19 @@ def p_sample_ddim(sd, cfg, layouts, sched, x, cond, uncond, index, step, cfg_sca
     return x_prev.astype(F32), pred_x0.astype(F32), e_t.astype(F32)
 
 
+def q_sample(cfg, x_start, t, noise):
+    """DDPM.q_sample, ldm/models/diffusion/ddpm.py:356-359, on the fp32 buffers of register_schedule (:162-163)."""
+    betas = np.linspace(cfg.linear_start ** 0.5, cfg.linear_end ** 0.5, cfg.timesteps, dtype=np.float64) ** 2
+    ac = np.cumprod(1.0 - betas)
+    sa = np.sqrt(ac).astype(F32)[t].reshape(-1, 1, 1, 1)
+    sb = np.sqrt(1.0 - ac).astype(F32)[t].reshape(-1, 1, 1, 1)
+    return (sa * x_start + sb * noise).astype(F32)
+
+
 def ddim_sampling(sd, cfg, layouts, S, x_T, cond, uncond, cfg_scale, eta=0.0, control_scales=None,
-                  noises=None, steps_limit: Optional[int] = None):
+                  noises=None, steps_limit: Optional[int] = None, mask=None, x0=None, q_noise=None):
     """DDIMSampler.sample + ddim_sampling, cldm/ddim_hacked.py:55-178 with log_every_t=1.
+    mask/x0: the inpainting blend of :154-157, with the q_sample noise of each step supplied (q_noise[i]).
 
     Returns (samples, x_inter list of S+1 latents, pred_x0 list)."""
     sched = make_schedule(S, eta, cfg.timesteps, cfg.linear_start, cfg.linear_end)
@@ -346,6 +356,9 @@ def ddim_sampling(sd, cfg, layouts, S, x_T, cond, uncond, cfg_scale, eta=0.0, co
         if steps_limit is not None and i >= steps_limit:
             break
         index = S - i - 1
+        if mask is not None:
+            img_orig = q_sample(cfg, x0, np.full((img.shape[0],), int(step), np.int64), q_noise[i])
+            img = (img_orig * mask + (F32(1.0) - mask) * img).astype(F32)
         nz = None if noises is None else noises[i]
         img, pred_x0, _ = p_sample_ddim(sd, cfg, layouts, sched, img, cond, uncond, index, int(step),
                                         cfg_scale, control_scales, nz)

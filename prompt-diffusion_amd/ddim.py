@@ -33,6 +33,12 @@ def _cat(xs):
     return np.concatenate(list(xs), 1)
 
 
+def _np32(x):
+    if E._is_torch(x):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x, np.float32)
+
+
 class ControlLDM:
     """The attributes of cldm.cldm.ControlLDM the sampler touches, backed by an Engine."""
 
@@ -42,6 +48,22 @@ class ControlLDM:
         self.only_mid_control = False             # cldm/cldm.py:334
         self.num_timesteps = engine.cfg.timesteps
         self.parameterization = "eps"
+        # DDPM.register_schedule buffers q_sample reads (ddpm.py:138-163): fp64 schedule, stored fp32
+        cfg = engine.cfg
+        betas = np.linspace(cfg.linear_start ** 0.5, cfg.linear_end ** 0.5, cfg.timesteps, dtype=np.float64) ** 2
+        ac = np.cumprod(1.0 - betas)
+        self.sqrt_alphas_cumprod = np.sqrt(ac).astype(np.float32)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - ac).astype(np.float32)
+
+    def q_sample(self, x_start, t, noise=None):
+        """DDPM.q_sample, ldm/models/diffusion/ddpm.py:356-359 (host arithmetic; used by the inpainting blend)."""
+        x_start = _np32(x_start)
+        if noise is None:
+            noise = np.random.standard_normal(x_start.shape).astype(np.float32)
+        t = np.asarray(t, np.int64).reshape(-1)
+        sa = self.sqrt_alphas_cumprod[t].reshape(-1, 1, 1, 1)
+        sb = self.sqrt_one_minus_alphas_cumprod[t].reshape(-1, 1, 1, 1)
+        return (sa * x_start + sb * np.asarray(noise, np.float32)).astype(np.float32)
 
     def apply_model(self, x_noisy, t, cond, *args, **kwargs):
         """eps = apply_model(x, t, cond), cldm/cldm.py:369-382 (one HIP pass through ControlNet + UNet)."""
@@ -77,7 +99,7 @@ class DDIMSampler:
                unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None, noise=None, **kwargs):
         if conditioning is None or not isinstance(conditioning, dict):
             raise NotImplementedError("conditioning must be the ControlLDM dict (c_crossattn / example_pair / query)")
-        for name, val in (("mask", mask), ("score_corrector", score_corrector), ("dynamic_threshold", dynamic_threshold),
+        for name, val in (("score_corrector", score_corrector), ("dynamic_threshold", dynamic_threshold),
                           ("ucg_schedule", ucg_schedule), ("normals_sequence", normals_sequence)):
             if val is not None:
                 raise NotImplementedError(f"{name} is not supported by the HIP sampler")
@@ -113,7 +135,17 @@ class DDIMSampler:
         # per-step export (asynchronous launches; the host only syncs when it reads latents back)
         n = eng.sample_begin(**kw)
         x_inter, preds = [x_T], [x_T]
+        if mask is not None:
+            assert x0 is not None                          # ddim_hacked.py:155
+            mask_np = _np32(mask)
+            x0_np = _np32(x0)
         for i in range(n):
+            if mask is not None:
+                # inpainting blend, ddim_hacked.py:154-157: keep the known region at this step's noise level
+                ts = np.full((batch_size,), int(self.ddim_timesteps[n - i - 1]), np.int64)
+                img_orig = _np32(self.model.q_sample(x0_np, ts))
+                cur = _np32(eng.sample_get(E.PD_GET_LATENTS))
+                eng.sample_set_latents(img_orig * mask_np + (np.float32(1.0) - mask_np) * cur)
             eng.sample_step(i)
             index = n - i - 1
             if callback:

@@ -118,6 +118,12 @@ def build_reference(cfg, W):
     m.parameterization = "eps"
     m.device = torch.device("cpu")
     m.apply_model = lambda x, t, c: ControlLDM.apply_model(m, x, t, c)
+    # q_sample (inpainting blend, ddim_hacked.py:154-157): the reference's own DDPM.q_sample, unbound, on the buffers
+    # register_schedule creates (ddpm.py:162-163)
+    from ldm.models.diffusion.ddpm import DDPM
+    m.sqrt_alphas_cumprod = torch.tensor(np.sqrt(ac), dtype=torch.float32)
+    m.sqrt_one_minus_alphas_cumprod = torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32)
+    m.q_sample = lambda x_start, t, noise=None: DDPM.q_sample(m, x_start, t, noise)
     return m, cn, un
 
 
@@ -177,6 +183,37 @@ def run_net_case(tag, cfg, W, B, h, w, S, cfg_scale, eta, out):
     np.savez_compressed(os.path.join(out, f"net_{tag}.npz"), **res)
     print(f"[golden] net_{tag}: eps |mean| {np.abs(res['eps']).mean():.4f}, "
           f"x_final |mean| {np.abs(res['samples']).mean():.4f}")
+
+
+def run_mask_case(tag, cfg, W, B, h, w, S, cfg_scale, out):
+    """DDIMSampler.sample(mask=..., x0=...) (ddim_hacked.py:154-157): q_sample draws noise with torch.randn_like; the
+    draws are recorded so the blend can be replayed with the same noise."""
+    model, cn, un = build_reference(cfg, W)
+    inp = W.synth_inputs(cfg, B, h, w, seed=31)
+    tt = {k: torch.from_numpy(v) for k, v in inp.items()}
+    cond = {"c_crossattn": [tt["ctx_cond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    uc = {"c_crossattn": [tt["ctx_uncond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    g = np.random.default_rng(32)
+    x0 = torch.from_numpy(g.standard_normal((B, cfg.in_channels, h, w)).astype(np.float32))
+    mask = torch.from_numpy((g.random((B, 1, h, w)) > 0.5).astype(np.float32))
+    noises = []
+    from ldm.models.diffusion.ddpm import DDPM
+
+    def q_sample(x_start, t, noise=None):
+        n = torch.randn_like(x_start)
+        noises.append(t2n(n))
+        return DDPM.q_sample(model, x_start, t, n)
+    model.q_sample = q_sample
+    sampler = make_sampler(model)
+    torch.manual_seed(33)
+    with torch.no_grad():
+        samples, inter = sampler.sample(S, B, (cfg.in_channels, h, w), cond, eta=0.0, x_T=tt["x_T"], mask=mask, x0=x0,
+                                        unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc,
+                                        log_every_t=1, verbose=False)
+    np.savez_compressed(os.path.join(out, f"net_{tag}.npz"), B=B, h=h, w=w, S=S, cfg_scale=cfg_scale, seed=31,
+                        x0=t2n(x0), mask=t2n(mask), q_noise=np.stack(noises), samples=t2n(samples),
+                        x_inter=np.stack([t2n(x) for x in inter["x_inter"]]))
+    print(f"[golden] net_{tag}: {len(noises)} q_sample draws, x_final |mean| {np.abs(t2n(samples)).mean():.4f}")
 
 
 def run_op_cases(cfg, W, out):
@@ -323,6 +360,8 @@ def main():
     if want("tiny"):
         run_net_case("tiny_b2_16x16_s5", W.TINY, W, B=2, h=16, w=16, S=5, cfg_scale=7.5, eta=0.0, out=out)
         run_net_case("tiny_b1_8x24_s4", W.TINY, W, B=1, h=8, w=24, S=4, cfg_scale=9.0, eta=0.0, out=out)
+    if want("mask"):
+        run_mask_case("tiny_mask_b2_16x16_s5", W.TINY, W, B=2, h=16, w=16, S=5, cfg_scale=7.5, out=out)
     if want("sd15") and not args.skip_sd15:
         # BASELINE config #1: 256x256 (latent 32x32), 5 DDIM steps, bs=1, CFG
         run_net_case("sd15_b1_32x32_s5", W.SD15, W, B=1, h=32, w=32, S=5, cfg_scale=7.5, eta=0.0, out=out)

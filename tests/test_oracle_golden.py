@@ -109,6 +109,24 @@ def test_tiny_network_and_sampler(golden_dir, tag):
         assert relerr(preds[i], g["pred_x0"][i]) < 1e-4, i
 
 
+def test_inpainting_blend_matches_reference(golden_dir):
+    """DDIMSampler.sample(mask=, x0=) (ddim_hacked.py:154-157 + DDPM.q_sample): reference run with the q_sample noise
+    draws recorded; the oracle replays the blend with the same draws."""
+    cfg = W.TINY
+    g = np.load(os.path.join(golden_dir, "net_tiny_mask_b2_16x16_s5.npz"))
+    B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
+    inp = W.synth_inputs(cfg, B, h, w, seed=int(g["seed"]))
+    sd = W.synth_state_dict(cfg)
+    lay = O.make_layouts(cfg, W)
+    cond = dict(c_crossattn=inp["ctx_cond"], example_pair=inp["pair"], query=inp["query"])
+    unc = dict(c_crossattn=inp["ctx_uncond"], example_pair=inp["pair"], query=inp["query"])
+    samples, x_inter, _ = O.ddim_sampling(sd, cfg, lay, S, inp["x_T"], cond, unc, float(g["cfg_scale"]),
+                                          mask=g["mask"], x0=g["x0"], q_noise=g["q_noise"])
+    for i in range(S + 1):
+        assert relerr(x_inter[i], g["x_inter"][i]) < 1e-4, i
+    assert relerr(samples, g["samples"]) < 1e-4
+
+
 @pytest.mark.slow
 def test_sd15_config1_first_and_last_step(golden_dir):
     """BASELINE config #1 (256x256, 5 DDIM steps, bs 1): replay steps 0 and 4 of the reference

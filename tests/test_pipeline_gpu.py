@@ -55,6 +55,28 @@ def test_ddim_sampler_surface_matches_reference_run(golden_dir, eng):
     assert relerr(eps, g["eps"][B:]) < 2e-4
 
 
+def test_ddim_sampler_inpainting_mask_matches_reference_run(golden_dir, eng):
+    """sample(mask=, x0=): the blend of ddim_hacked.py:154-157 through the per-step export, against the reference's
+    own run (q_sample noise draws replayed from the fixture)."""
+    g = np.load(os.path.join(golden_dir, "net_tiny_mask_b2_16x16_s5.npz"))
+    B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
+    inp = W.synth_inputs(W.TINY, B, h, w, seed=int(g["seed"]))
+    model = ControlLDM(eng)
+    draws = iter(g["q_noise"])
+    model.q_sample = lambda x, t, noise=None: ControlLDM.q_sample(model, x, t, next(draws))
+    sampler = DDIMSampler(model)
+    cond = {"c_crossattn": [inp["ctx_cond"]], "example_pair": [inp["pair"]], "query": [inp["query"]]}
+    uc = {"c_crossattn": [inp["ctx_uncond"]], "example_pair": [inp["pair"]], "query": [inp["query"]]}
+    samples, inter = sampler.sample(S, B, (4, h, w), cond, eta=0.0, x_T=inp["x_T"], mask=g["mask"], x0=g["x0"],
+                                    unconditional_guidance_scale=float(g["cfg_scale"]), unconditional_conditioning=uc,
+                                    log_every_t=1, verbose=False)
+    for i in range(S + 1):
+        assert relerr(inter["x_inter"][i], g["x_inter"][i]) < 3e-4, i
+    assert relerr(samples, g["samples"]) < 3e-4
+    with pytest.raises(AssertionError):
+        sampler.sample(S, B, (4, h, w), cond, eta=0.0, x_T=inp["x_T"], mask=g["mask"], unconditional_conditioning=uc)
+
+
 def _oracle_pipeline(cfg, sd, lay, x_T, pe, ne, pair, query, S, gs, scale, guess, g_start, g_end):
     """Replay of pipeline_prompt_diffusion.py:1196-1273 with the oracle's networks and a DDIM step."""
     sched = O.make_schedule(S)
