@@ -72,7 +72,13 @@ typedef struct pd_config {
     int32_t vae_num_res_blocks; /* 2 */
     int32_t vae_out_ch;       /* 3 */
     double scale_factor;      /* 0.18215, cldm_v15.yaml:17 */
-    int32_t reserved[6];
+    /* cond-stage CLIP text transformer (ldm/modules/encoders/modules.py:88-131).  Width = context_dim,
+     * length = context_len.  text_layers = 0: not built */
+    int32_t text_vocab;       /* 49408 */
+    int32_t text_layers;      /* 12 */
+    int32_t text_heads;       /* 12 */
+    int32_t text_ff;          /* 3072 */
+    int32_t reserved[2];
 } pd_config;
 
 /* Arguments of one sampling call (replaces DDIMSampler.sample's arguments,
@@ -179,6 +185,13 @@ int pd_profile_dump(pd_engine* e, const char* csv_path); /* one row per profiled
  * stream; returns average ms per launch in *ms. */
 int pd_bench_conv3x3(pd_engine* e, int32_t Bf, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      int32_t iters, float* ms);
+
+/* Cond stage (replaces FrozenCLIPEmbedder.forward after tokenisation, ldm/modules/encoders/modules.py:118-128, and
+ * text_encoder(ids)[0] in PromptDiffusionPipeline.encode_prompt, pipeline_prompt_diffusion.py:308-487): token ids
+ * [B, context_len] int32 -> last_hidden_state [B, context_len, context_dim] fp32.  mem: PD_MEM_HOST / PD_MEM_DEVICE for both
+ * buffers.  Needs the cond_stage_model.transformer.text_model.* weights (pd_text_weights_missing() == 0). */
+int pd_text_encode(pd_engine* e, const int32_t* ids, int32_t B, int32_t mem, float* out);
+int pd_text_weights_missing(pd_engine* e);
 
 /* Same for one Linear / conv1x1 layer ([M,K] x [N,K]^T, optional residual add) in isolation. */
 int pd_bench_linear(pd_engine* e, int32_t M, int32_t K, int32_t N, int32_t residual, int32_t iters, float* ms);

@@ -469,3 +469,36 @@ def unipc2_sample(eps_fn, x_T, alphas_cumprod, timesteps):
         m_pp, m_prev, prev_order = m_prev, m, order
         x = x_next
     return x
+
+
+# ---------------------------------------------------------------------------------------------------
+# CLIP text transformer: FrozenCLIPEmbedder.forward, ldm/modules/encoders/modules.py:118-128
+# (layer "last": `outputs.last_hidden_state`), i.e. transformers' CLIPTextModel: token + position embeddings,
+# pre-LN blocks with causal self-attention and quick-GELU MLP, final LayerNorm.  The model code lives in the
+# `transformers` dependency (not in the reference tree); this restates its published architecture and is pinned against
+# `transformers.CLIPTextModel` itself run in the build container (tests/golden/make_golden.py, clip_*.npz).
+def clip_text_forward(sd, cfg, ids, prefix="cond_stage_model.transformer.text_model."):
+    p = lambda n: sd[prefix + n]
+    B, L = ids.shape
+    C, H = cfg.context_dim, cfg.text_heads
+    dh = C // H
+    x = p("embeddings.token_embedding.weight")[ids] + p("embeddings.position_embedding.weight")[None, :L]
+    causal = np.triu(np.full((L, L), -np.inf, F32), k=1)
+    for i in range(cfg.text_layers):
+        pre = f"encoder.layers.{i}."
+        h = layer_norm(x, p(pre + "layer_norm1.weight"), p(pre + "layer_norm1.bias"), eps=1e-5)
+        q = linear(h, p(pre + "self_attn.q_proj.weight"), p(pre + "self_attn.q_proj.bias")) * F32(dh ** -0.5)
+        k = linear(h, p(pre + "self_attn.k_proj.weight"), p(pre + "self_attn.k_proj.bias"))
+        v = linear(h, p(pre + "self_attn.v_proj.weight"), p(pre + "self_attn.v_proj.bias"))
+        sp = lambda t: t.reshape(B, L, H, dh).transpose(0, 2, 1, 3)
+        s_ = np.einsum("bhid,bhjd->bhij", sp(q), sp(k)) + causal
+        s_ = s_ - s_.max(-1, keepdims=True)
+        e = np.exp(s_)
+        a = e / e.sum(-1, keepdims=True)
+        o = np.einsum("bhij,bhjd->bhid", a, sp(v)).transpose(0, 2, 1, 3).reshape(B, L, C)
+        x = x + linear(o, p(pre + "self_attn.out_proj.weight"), p(pre + "self_attn.out_proj.bias"))
+        h = layer_norm(x, p(pre + "layer_norm2.weight"), p(pre + "layer_norm2.bias"), eps=1e-5)
+        h = linear(h, p(pre + "mlp.fc1.weight"), p(pre + "mlp.fc1.bias"))
+        h = h * (F32(1.0) / (F32(1.0) + np.exp(F32(-1.702) * h)))                 # quick_gelu
+        x = x + linear(h, p(pre + "mlp.fc2.weight"), p(pre + "mlp.fc2.bias"))
+    return layer_norm(x, p("final_layer_norm.weight"), p("final_layer_norm.bias"), eps=1e-5).astype(F32)

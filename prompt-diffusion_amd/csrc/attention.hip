@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 for (int j = 0; j < 4; ++j) {
                     const int key = t0 + kt * 16 + fq * 4 + j;
                     float v = s[kt][qt][j] * sl2;
-                    v = key < p.Nk ? v : -INFINITY;
+                    v = (key < p.Nk && (!p.causal || key <= q0 + qt * 16 + fr)) ? v : -INFINITY;
                     s[kt][qt][j] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -422,12 +422,16 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
                 mma16<false>(kf, qf[ks][1], s[kt][1]);
             }
         }
-        if (t0 + TK > p.Nk) {  // ragged last tile: mask the pad keys
+        if (t0 + TK > p.Nk || p.causal) {  // ragged last tile: mask the pad keys; causal: the keys after the query
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (t0 + kt * 16 + fq * 4 + j >= p.Nk) { s[kt][0][j] = -INFINITY; s[kt][1][j] = -INFINITY; }
+                for (int j = 0; j < 4; ++j) {
+                    const int key = t0 + kt * 16 + fq * 4 + j;
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        if (key >= p.Nk || (p.causal && key > q0 + qt * 16 + fr)) s[kt][qt][j] = -INFINITY;
+                }
         }
         if constexpr (SUBM) {
             float mx[2];

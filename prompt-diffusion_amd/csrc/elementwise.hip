@@ -51,6 +51,25 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
+__global__ void embed_tokens_kernel(const int* __restrict__ ids, const void* __restrict__ tok, int tok_ld, const void* __restrict__ pos,
+                                    int pos_ld, int dt, void* __restrict__ out, int out_dt, int B, int L, int C, int vocab) {
+    const long long total = (long long)B * L * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long bl = i / C;
+        const int l = (int)(bl % L);
+        int id = ids[bl];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        float v;
+        if (dt == DT_F32)
+            v = reinterpret_cast<const float*>(tok)[(size_t)id * tok_ld + c] + reinterpret_cast<const float*>(pos)[(size_t)l * pos_ld + c];
+        else
+            v = bf2f(reinterpret_cast<const uint16_t*>(tok)[(size_t)id * tok_ld + c]) + bf2f(reinterpret_cast<const uint16_t*>(pos)[(size_t)l * pos_ld + c]);
+        if (out_dt == DT_F32) reinterpret_cast<float*>(out)[i] = v;
+        else reinterpret_cast<uint16_t*>(out)[i] = f2bf(v);
+    }
+}
+
 __global__ void nhwc_to_nchw_kernel(const void* __restrict__ in, int in_dt, float* __restrict__ out, int B, int C,
                                     int HW, int Cpad, float scale) {
     const long long total = (long long)B * C * HW;
@@ -197,6 +216,12 @@ int launch_nchw_to_nhwc(const float* in, void* out, int out_dt, int B, int C, in
 }
 int launch_softmax_rows(const float* in, void* out, int out_dt, int rows, int n, hipStream_t s) {
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, out, out_dt, rows, n);
+    CHECK_LAUNCH();
+}
+int launch_embed_tokens(const int* ids, const void* tok, int tok_ld, const void* pos, int pos_ld, int dt, void* out, int out_dt,
+                        int B, int L, int C, int vocab, hipStream_t s) {
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(nblocks((long long)B * L * C)), dim3(TPB), 0, s, ids, tok, tok_ld, pos, pos_ld, dt,
+                       out, out_dt, B, L, C, vocab);
     CHECK_LAUNCH();
 }
 int launch_nhwc_to_nchw(const void* in, int in_dt, float* out, int B, int C, int H, int W, int Cpad, float scale, hipStream_t s) {

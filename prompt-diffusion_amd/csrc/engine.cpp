@@ -298,6 +298,7 @@ int pd_engine::build() {
         build_conv(P + "middle_block_out.0.", n.mid_out, ch, ch, 1, 1);
     }
     build_vae();
+    build_text();
     if ((int)cnet.enc.size() + 1 != PD_NUM_CONTROL && verbose)
         fprintf(stderr, "[pdengine] note: %zu control tensors (reference SD1.5 has 13)\n", cnet.enc.size() + 1);
     if ((int)cnet.enc.size() + 1 > PD_NUM_CONTROL) {
@@ -691,7 +692,8 @@ int pd_engine::layernorm(const Act& x, Act& y, const float* g, const float* b) {
 }
 
 int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B,
-                         int Nq, int Nk, int C) {
+                         int Nq, int Nk, int C, int heads, bool causal) {
+    if (heads <= 0) heads = cfg.num_heads;
     if (arena.dry) return 0;
     AttnParams p{};
     p.Q = Q; p.K = K; p.VT = VT; p.O = O;
@@ -700,14 +702,15 @@ int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const v
     p.k_bs = (long long)Nk * ldk;
     p.vt_bs = (long long)C * vt_ld;
     p.o_bs = (long long)Nq * ldo;
-    p.Nq = Nq; p.Nk = Nk; p.heads = cfg.num_heads; p.dh = C / cfg.num_heads;
+    p.Nq = Nq; p.Nk = Nk; p.heads = heads; p.dh = C / heads;
+    p.causal = causal ? 1 : 0;
     p.scale = (float)(1.0 / std::sqrt((double)p.dh));
     p.B = B;
     p.legacy = opt_attn_legacy ? 1 : 0;
     ++launches;
     ProfRec rec{};
     if (profiling) {
-        prof_begin(rec, 2, 4.0 * (double)B * cfg.num_heads * (double)Nq * (double)Nk * (double)p.dh);
+        prof_begin(rec, 2, 4.0 * (double)B * heads * (double)Nq * (double)Nk * (double)p.dh);
         rec.M = Nq; rec.N = Nk; rec.K = p.dh; rec.taps = B;
     }
     const int r = launch_attention(p, f32, stream);

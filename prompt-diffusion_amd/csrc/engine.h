@@ -116,6 +116,18 @@ struct VaeW {
     int top = 0;
 };
 
+// CLIP text transformer
+struct TextLayerW {
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    WMat qkv, out, fc1, fc2;
+};
+struct TextW {
+    bool built = false;
+    WMat tok, pos;
+    std::vector<TextLayerW> layers;
+    float *fln_g = nullptr, *fln_b = nullptr;
+};
+
 struct Param {
     std::string name;
     std::vector<int64_t> shape;
@@ -130,7 +142,7 @@ struct Param {
     bool conv = false;  // OIHW source
     char init = 'w';    // recipe class for pd_init_random_weights: w, b, g(amma), e(beta)
     bool loaded = false;
-    int group = 0;      // 0: UNet + ControlNet (needed to sample), 1: VAE decoder
+    int group = 0;      // 0: UNet + ControlNet (needed to sample), 1: VAE decoder, 2: text transformer
 };
 
 struct Act {
@@ -193,6 +205,7 @@ struct pd_engine {
     std::unordered_map<std::string, int> index;
     NetW unet, cnet;
     VaeW vae;
+    TextW text;
     int reg_group = 0;
     std::vector<void*> owned;  // device allocations (weights)
     size_t weight_bytes = 0;
@@ -254,6 +267,8 @@ struct pd_engine {
     void build_middle(const std::string& prefix, NetW& net);
     void build_vres(const std::string& prefix, ResW& r, int cin, int cout);
     void build_vae();
+    void build_text();
+    int text_forward(const int* ids_dev, int B, float* out_dev);
     int vae_forward(const float* latents_dev, int B, int h, int w, float* out_dev);
     int vae_attention(const Act& x, Act& out);
 
@@ -278,7 +293,7 @@ struct pd_engine {
     int resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride);
     int transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv);
     int attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B, int Nq,
-                  int Nk, int C);
+                  int Nk, int C, int heads = 0, bool causal = false);
 
     // networks
     int run_controlnet(const Act& x_in, int emb_row, int emb_stride, const float* scales);

@@ -117,6 +117,7 @@ struct AttnParams {
     float scale;
     int B;
     int legacy;  // 1: use the single-buffered reference kernel (debug)
+    int causal;  // keys after the query are masked (CLIP text transformer)
 };
 
 int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid = nullptr);
@@ -136,6 +137,9 @@ int launch_layernorm(const void* x, int x_dt, void* y, int y_dt, const float* ga
 int launch_nchw_to_nhwc(const float* in, void* out, int out_dt, int B, int C, int H, int W, int Cpad, hipStream_t s,
                         float scale = 1.0f);
 int launch_softmax_rows(const float* in, void* out, int out_dt, int rows, int n, hipStream_t s);
+// out[b,l,:] = tok[ids[b,l]] + pos[l]  (CLIP text embeddings); tables are [rows][ld] in dtype dt
+int launch_embed_tokens(const int* ids, const void* tok, int tok_ld, const void* pos, int pos_ld, int dt, void* out, int out_dt,
+                        int B, int L, int C, int vocab, hipStream_t s);
 int launch_nhwc_to_nchw(const void* in, int in_dt, float* out, int B, int C, int H, int W, int Cpad, float scale, hipStream_t s);
 int launch_cast_rows(const float* in, void* out, int out_dt, long long rows, int C, int Cpad, hipStream_t s);
 int launch_concat_add(const void* a, const void* a_add, const void* b, const void* b_add, void* out, int dt,

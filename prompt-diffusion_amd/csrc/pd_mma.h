@@ -51,6 +51,9 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int gm, int gn, i
     if (p.act == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+    } else if (p.act == 3) {   // quick_gelu: x * sigmoid(1.702 x)  (CLIP MLP)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
     }
     v *= p.out_scale;
     if (p.R) v += load4(p.R, (size_t)gm * p.ldr + gn, p.r_dt);

@@ -351,6 +351,14 @@ int pd_engine_create(const pd_config* cfg, int device_id, pd_engine** out) {
         return 10;
     }
     if (device_id < 0 || device_id >= ndev) { pd_set_error("device %d out of range (%d visible)", device_id, ndev); return 1; }
+    if (cfg->text_layers > 0) {
+        const int th = cfg->text_heads, dh = th > 0 && cfg->context_dim % th == 0 ? cfg->context_dim / th : 0;
+        if (dh != 8 && dh != 16 && dh != 32 && dh != 40 && dh != 64 && dh != 80 && dh != 160) {
+            pd_set_error("text transformer: context_dim %d / text_heads %d is not a supported head size", cfg->context_dim, th);
+            return 1;
+        }
+        if (cfg->text_vocab < 1 || cfg->text_ff < 8 || cfg->text_ff % 8) { pd_set_error("text transformer: bad vocab / ff size"); return 1; }
+    }
     HIP_OK(hipSetDevice(device_id));
     pd_engine* e = new pd_engine();
     e->cfg = *cfg;

@@ -41,7 +41,8 @@ class pd_config(C.Structure):
         ("linear_end", C.c_double), ("precision", C.c_int32), ("stream_f32", C.c_int32),
         ("vae_ch", C.c_int32), ("vae_num_levels", C.c_int32), ("vae_ch_mult", C.c_int32 * PD_MAX_LEVELS),
         ("vae_num_res_blocks", C.c_int32), ("vae_out_ch", C.c_int32), ("scale_factor", C.c_double),
-        ("reserved", C.c_int32 * 6),
+        ("text_vocab", C.c_int32), ("text_layers", C.c_int32), ("text_heads", C.c_int32), ("text_ff", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -60,6 +61,23 @@ class pd_sample_args(C.Structure):
 _lib = None
 
 
+def _torch_runtime_first():
+    """PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so) under the same soname as the system one that
+    libpdengine.so links.  The dynamic loader keeps whichever is loaded first for the whole process: with the system
+    runtime first, torch (built against its own) later reports "No HIP GPUs are available"; with torch's first, both
+    work.  So when torch is installed, load it -- and bring its device runtime up -- before libpdengine.so is opened.
+    CUDA tensors can then be handed to the engine as device pointers whatever the caller's import order."""
+    try:
+        import torch
+    except ImportError:
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:   # noqa: BLE001 - torch without a usable device: the engine reports the real error
+        pass
+
+
 def load_library(path: Optional[str] = None) -> C.CDLL:
     """dlopen libpdengine.so and declare the prototypes of include/pdengine.h."""
     global _lib
@@ -69,6 +87,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if not os.path.exists(p):
         raise PdError(f"{p} not found: build it with `make -C {_CSRC}` (or __graft_entry__.build()); "
                       "pdengine has no CPU fallback")
+    _torch_runtime_first()
     lib = C.CDLL(p)
     lib.pd_last_error.restype = C.c_char_p
     lib.pd_abi_version.restype = C.c_int
@@ -82,6 +101,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_weights_missing.argtypes = [C.c_void_p]
     lib.pd_vae_weights_missing.argtypes = [C.c_void_p]
     lib.pd_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.pd_text_weights_missing.argtypes = [C.c_void_p]
+    lib.pd_text_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.pd_eps.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]
     lib.pd_control_shape.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 3
     lib.pd_ddim_sample.argtypes = [C.c_void_p, C.POINTER(pd_sample_args), C.c_int32, C.c_void_p, C.c_void_p]
@@ -118,7 +139,7 @@ EXPORTS = [
     "pd_last_error", "pd_abi_version", "pd_engine_create", "pd_engine_destroy", "pd_param_count", "pd_param_info",
     "pd_load_weights", "pd_init_random_weights", "pd_weights_missing", "pd_vae_weights_missing", "pd_vae_decode", "pd_eps", "pd_control_shape", "pd_ddim_sample",
     "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_eps_at", "pd_sample_end",
-    "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear",
+    "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_weights_missing",
     "pd_profile_read", "pd_profile_dump",
     "pd_op_conv2d", "pd_op_linear", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention",
 ]
@@ -149,6 +170,7 @@ def make_config(cfg: ModelConfig, precision: int = PD_PREC_BF16, stream_f32: boo
     for i, m in enumerate(cfg.vae_ch_mult):
         c.vae_ch_mult[i] = m
     c.vae_num_res_blocks, c.vae_out_ch, c.scale_factor = cfg.vae_num_res_blocks, cfg.vae_out_ch, cfg.scale_factor
+    c.text_vocab, c.text_layers, c.text_heads, c.text_ff = cfg.text_vocab, cfg.text_layers, cfg.text_heads, cfg.text_ff
     return c
 
 
@@ -179,6 +201,7 @@ class Engine:
 
     def __init__(self, cfg: ModelConfig = SD15, device: int = 0, precision: str = "bf16", stream_f32: bool = False,
                  lib_path: Optional[str] = None):
+        _torch_runtime_first()
         self.lib = load_library(lib_path)
         self.cfg = cfg
         self.precision = {"bf16": PD_PREC_BF16, "f32": PD_PREC_F32, "fp32": PD_PREC_F32}[precision]
@@ -257,6 +280,28 @@ class Engine:
             out = np.empty((B, self.cfg.vae_out_ch, 8 * h, 8 * w), np.float32)
             op = out.ctypes.data
         self._check(self.lib.pd_vae_decode(self._h, b.ptr, B, h, w, b.mem, op))
+        return out
+
+    def text_weights_missing(self) -> int:
+        return int(self.lib.pd_text_weights_missing(self._h))
+
+    def text_encode(self, input_ids):
+        """FrozenCLIPEmbedder.forward after tokenisation (ldm/modules/encoders/modules.py:118-128): token ids
+        [B, context_len] -> last_hidden_state [B, context_len, context_dim] fp32 (NumPy in, NumPy out; CUDA int32 tensor in,
+        CUDA tensor out)."""
+        if _is_torch(input_ids):
+            import torch
+            ids = input_ids.to(torch.int32).contiguous()
+            if ids.is_cuda:
+                out = torch.empty(tuple(ids.shape) + (self.cfg.context_dim,), dtype=torch.float32, device=ids.device)
+                self._check(self.lib.pd_text_encode(self._h, ids.data_ptr(), ids.shape[0], PD_MEM_DEVICE, out.data_ptr()))
+                return out
+            input_ids = ids.numpy()
+        ids = np.ascontiguousarray(input_ids, np.int32)
+        if ids.ndim != 2 or ids.shape[1] != self.cfg.context_len:
+            raise ValueError(f"input_ids must be [B, {self.cfg.context_len}]")
+        out = np.empty(ids.shape + (self.cfg.context_dim,), np.float32)
+        self._check(self.lib.pd_text_encode(self._h, ids.ctypes.data, ids.shape[0], PD_MEM_HOST, out.ctypes.data))
         return out
 
     # ------------------------------------------------------------------ operator boundary

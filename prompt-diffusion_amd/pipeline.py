@@ -7,8 +7,10 @@ promptdiffusioncontrolnet.py:371-375), ``controlnet_keep`` gating from ``control
 (:1196-1202), guess-mode zero residuals for the unconditional half (:1248-1253), ``[negative, positive]``
 CFG order (:1108, :1269-1270).  The denoising loop itself runs in the HIP engine.
 
-Out of the hot path, so injected rather than built here:
-  * ``text_encoder(list_of_prompts) -> [B, 77, 768]`` -- without it pass ``prompt_embeds`` /
+Either side of the hot path:
+  * the text encoder: ``tokenizer=`` (a transformers CLIPTokenizer or a callable prompts -> ids [B, 77]) runs the CLIP text
+    transformer inside the engine (``pd_text_encode``) when the checkpoint's ``cond_stage_model.*`` tensors are
+    loaded; a ``text_encoder(list_of_prompts) -> [B, 77, 768]`` callable overrides it; with neither pass ``prompt_embeds`` /
     ``negative_prompt_embeds`` (the north star consumes the CLIP embedding as a fixed context tensor);
   * the VAE decoder: built into the engine (``pd_vae_decode``) when the checkpoint's ``first_stage_model.*``
     tensors are loaded; a ``vae_decode(latents / scaling_factor) -> images in [-1, 1]`` callable overrides it; with
@@ -47,8 +49,13 @@ class PromptDiffusionPipeline:
     vae_scaling_factor = 0.18215      # models/cldm_v15.yaml:17
 
     def __init__(self, engine: E.Engine, text_encoder: Optional[Callable] = None, vae_decode: Optional[Callable] = None,
-                 scheduler: Any = None):
+                 scheduler: Any = None, tokenizer: Any = None):
         self.engine = engine
+        self.tokenizer = tokenizer
+        if text_encoder is None and tokenizer is not None:
+            # cond stage inside the engine (pd_text_encode): the caller only supplies the tokenizer -- a
+            # transformers CLIPTokenizer, or any callable prompts -> token ids [B, context_len]
+            text_encoder = self._engine_text_encoder
         self.text_encoder = text_encoder
         self.vae_decode = vae_decode
         self.scheduler = scheduler          # None = the engine's fused DDIM (DDIMScheduler semantics of SD1.5)
@@ -177,6 +184,25 @@ class PromptDiffusionPipeline:
                                    for g in generator])
         return torch.randn(shape, generator=generator, device=generator.device).cpu().numpy()
 
+    def _tokenize(self, prompts: List[str]):
+        """pipeline :386-392 / FrozenCLIPEmbedder.forward (modules.py:119-121): pad / truncate to context_len."""
+        L = self.engine.cfg.context_len
+        tok = self.tokenizer
+        if hasattr(tok, "model_max_length") or hasattr(tok, "pad_token_id"):      # transformers tokenizer
+            ids = tok(prompts, padding="max_length", max_length=L, truncation=True, return_tensors="np")["input_ids"]
+        else:
+            ids = tok(prompts)
+        ids = np.asarray(_to_numpy(ids), np.int32)
+        if ids.ndim != 2 or ids.shape != (len(prompts), L):
+            raise ValueError(f"tokenizer must return ids of shape [{len(prompts)}, {L}], got {ids.shape}")
+        return ids
+
+    def _engine_text_encoder(self, prompts: List[str]):
+        if self.engine.text_weights_missing() != 0:
+            raise ValueError("a string `prompt` needs the cond_stage_model.transformer.text_model.* weights in the engine "
+                             "(or a text_encoder callable, or `prompt_embeds`)")
+        return self.engine.text_encode(self._tokenize(prompts))
+
     def encode_prompt(self, prompt, num_images_per_prompt, do_cfg, negative_prompt=None, prompt_embeds=None,
                       negative_prompt_embeds=None):
         """pipeline :308-487 reduced to its tensor contract: returns (prompt_embeds, negative_prompt_embeds) [B*n, L, D]."""
@@ -224,8 +250,9 @@ class PromptDiffusionPipeline:
             raise NotImplementedError("ip_adapter_image is outside the hot path this engine replaces")
         if cross_attention_kwargs:
             raise NotImplementedError("cross_attention_kwargs (LoRA scale) is outside the hot path this engine replaces")
-        if clip_skip is not None and self.text_encoder is None:
-            raise NotImplementedError("clip_skip needs the text encoder, which is injected, not built (SURVEY.md N3)")
+        if clip_skip is not None:
+            raise NotImplementedError("clip_skip is not supported: pd_text_encode returns the last layer's output "
+                                      "(FrozenCLIPEmbedder layer=\"last\"); pass prompt_embeds computed with clip_skip instead")
         if timesteps is not None:
             raise NotImplementedError("custom `timesteps` are not supported by the fused DDIM loop")
         # 0/1. defaults + checks (pipeline :1033-1062)

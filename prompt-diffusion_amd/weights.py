@@ -53,6 +53,13 @@ class ModelConfig:
     vae_out_ch: int = 3
     scale_factor: float = 0.18215       # cldm_v15.yaml:17
 
+    # cond-stage CLIP text transformer (FrozenCLIPEmbedder -> CLIPTextModel "openai/clip-vit-large-patch14",
+    # ldm/modules/encoders/modules.py:88-131): width = context_dim, length = context_len (text_layers = 0: not built)
+    text_vocab: int = 49408
+    text_layers: int = 12
+    text_heads: int = 12
+    text_ff: int = 3072
+
     @property
     def time_embed_dim(self) -> int:
         return 4 * self.model_channels
@@ -62,7 +69,8 @@ SD15 = ModelConfig()
 # A reduced network with the same topology (4 levels, attention at ds 1/2/4,
 # 8 heads) used by fast parity tests: channels 64/128/256/256, dh 8/16/32.
 TINY = ModelConfig(model_channels=64, context_dim=96, context_len=77,
-                   hint_widths=(8, 8, 16, 16, 24, 24, 32), vae_ch=32)
+                   hint_widths=(8, 8, 16, 16, 24, 24, 32), vae_ch=32,
+                   text_vocab=1000, text_layers=2, text_heads=3, text_ff=192)
 
 Spec = Tuple[str, Tuple[int, ...], str]  # (name, shape, kind)
 
@@ -286,6 +294,50 @@ def vae_spec(cfg: ModelConfig, prefix: str = VAE_PREFIX) -> List[Spec]:
 
 def synth_vae_state_dict(cfg: ModelConfig, seed: int = 1234) -> Dict[str, np.ndarray]:
     return {n: synth_tensor(n, s, k, seed) for n, s, k in vae_spec(cfg)}
+
+
+TEXT_PREFIX = "cond_stage_model.transformer.text_model."
+
+
+def text_spec(cfg: ModelConfig, prefix: str = TEXT_PREFIX) -> List[Spec]:
+    """Parameters of the CLIP text transformer under the names the SD1.5 checkpoint stores them
+    (`FrozenCLIPEmbedder.transformer` = transformers' `CLIPTextModel`, ldm/modules/encoders/modules.py:98), in module
+    order: embeddings, encoder.layers.i.{self_attn.{k,v,q,out}_proj, layer_norm1, mlp.fc1/fc2, layer_norm2},
+    final_layer_norm."""
+    out: List[Spec] = []
+    if cfg.text_layers <= 0:
+        return out
+    C, F = cfg.context_dim, cfg.text_ff
+    out.append((prefix + "embeddings.token_embedding.weight", (cfg.text_vocab, C), "w"))
+    out.append((prefix + "embeddings.position_embedding.weight", (cfg.context_len, C), "w"))
+    for i in range(cfg.text_layers):
+        L = f"{prefix}encoder.layers.{i}."
+        for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            out.append((L + f"self_attn.{nm}.weight", (C, C), "w"))
+            out.append((L + f"self_attn.{nm}.bias", (C,), "b"))
+        out += [(L + "layer_norm1.weight", (C,), "gamma"), (L + "layer_norm1.bias", (C,), "beta")]
+        out += [(L + "mlp.fc1.weight", (F, C), "w"), (L + "mlp.fc1.bias", (F,), "b")]
+        out += [(L + "mlp.fc2.weight", (C, F), "w"), (L + "mlp.fc2.bias", (C,), "b")]
+        out += [(L + "layer_norm2.weight", (C,), "gamma"), (L + "layer_norm2.bias", (C,), "beta")]
+    out += [(prefix + "final_layer_norm.weight", (C,), "gamma"), (prefix + "final_layer_norm.bias", (C,), "beta")]
+    return out
+
+
+def synth_text_state_dict(cfg: ModelConfig, seed: int = 1234) -> Dict[str, np.ndarray]:
+    return {n: synth_tensor(n, s, k, seed) for n, s, k in text_spec(cfg)}
+
+
+def synth_token_ids(cfg: ModelConfig, batch: int, seed: int = 7) -> np.ndarray:
+    """Synthetic prompts: BOS, a run of random tokens, EOS padding to context_len (CLIPTokenizer pads with EOS for
+    openai/clip-vit-large-patch14); int32 [batch, context_len]."""
+    g = np.random.default_rng(seed)
+    bos, eos = cfg.text_vocab - 2, cfg.text_vocab - 1
+    ids = np.full((batch, cfg.context_len), eos, np.int32)
+    ids[:, 0] = bos
+    for b in range(batch):
+        n = int(g.integers(3, cfg.context_len - 2))
+        ids[b, 1:1 + n] = g.integers(0, cfg.text_vocab - 2, n)
+    return ids
 
 
 def num_params(cfg: ModelConfig) -> Tuple[int, int]:

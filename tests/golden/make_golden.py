@@ -216,6 +216,42 @@ def run_mask_case(tag, cfg, W, B, h, w, S, cfg_scale, out):
     print(f"[golden] net_{tag}: {len(noises)} q_sample draws, x_final |mean| {np.abs(t2n(samples)).mean():.4f}")
 
 
+def run_clip_case(tag, cfg, W, B, out):
+    """Cond-stage text transformer: the reference's FrozenCLIPEmbedder (ldm/modules/encoders/modules.py:88-131) wraps
+    transformers' CLIPTextModel and returns `last_hidden_state`; the tokenizer/checkpoint cannot be fetched offline, so
+    the module is built from its config with the seeded weights and fed synthetic token ids."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    tc = CLIPTextConfig(vocab_size=cfg.text_vocab, hidden_size=cfg.context_dim, intermediate_size=cfg.text_ff,
+                        num_hidden_layers=cfg.text_layers, num_attention_heads=cfg.text_heads,
+                        max_position_embeddings=cfg.context_len, hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                        bos_token_id=cfg.text_vocab - 2, eos_token_id=cfg.text_vocab - 1, pad_token_id=cfg.text_vocab - 1)
+    m = CLIPTextModel(tc).eval()
+    own = m.state_dict()
+    sd = W.synth_text_state_dict(cfg)
+    strip = W.TEXT_PREFIX
+    mapped = {}
+    for k, v in sd.items():
+        kk = k[len(strip):]
+        kk = kk if kk in own else "text_model." + kk      # transformers 4.x nests the weights under text_model.
+        mapped[kk] = torch.from_numpy(v)
+    missing = [k for k in own if k not in mapped and "position_ids" not in k]
+    assert not missing, missing
+    m.load_state_dict(mapped, strict=False)
+    ids = W.synth_token_ids(cfg, B)
+    with torch.no_grad():
+        z = m(input_ids=torch.from_numpy(ids).long()).last_hidden_state
+    z = t2n(z)
+    res = dict(B=B, ids=ids)
+    if z.size <= 200000:
+        res["z"] = z
+    else:
+        sub, stride = subsample(z, 16384)
+        res["z_sub"], res["z_stride"] = sub, stride
+    res["z_stats"] = np.array([z.mean(), np.abs(z).mean(), z.std(), np.abs(z).max()], np.float64)
+    np.savez_compressed(os.path.join(out, f"clip_{tag}.npz"), **res)
+    print(f"[golden] clip_{tag}: |z| mean {np.abs(z).mean():.4f}")
+
+
 def run_op_cases(cfg, W, out):
     """Per-operator fixtures from the reference's own modules."""
     from ldm.modules.diffusionmodules.openaimodel import ResBlock, Downsample, Upsample
@@ -328,6 +364,8 @@ def main():
     ap.add_argument("--skip-sd15", action="store_true")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
+    if not args.only or "clip" in args.only.split(","):
+        from transformers import CLIPTextModel  # noqa: F401  (before the stub modules go in: it probes torchvision)
     install_stubs()
     sys.path.insert(0, REF)
     os.chdir(REF)
@@ -360,6 +398,9 @@ def main():
     if want("tiny"):
         run_net_case("tiny_b2_16x16_s5", W.TINY, W, B=2, h=16, w=16, S=5, cfg_scale=7.5, eta=0.0, out=out)
         run_net_case("tiny_b1_8x24_s4", W.TINY, W, B=1, h=8, w=24, S=4, cfg_scale=9.0, eta=0.0, out=out)
+    if want("clip"):
+        run_clip_case("tiny_b3", W.TINY, W, 3, out)
+        run_clip_case("sd15_b2", W.SD15, W, 2, out)
     if want("mask"):
         run_mask_case("tiny_mask_b2_16x16_s5", W.TINY, W, B=2, h=16, w=16, S=5, cfg_scale=7.5, out=out)
     if want("sd15") and not args.skip_sd15:

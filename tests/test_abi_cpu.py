@@ -36,7 +36,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_struct_layout_matches_header(lib):
-    # sizes are part of the ABI: 35 int32 (+4 pad) + 2 double + 2 int32 + (2 + 8 + 2) int32 + double + 6 int32
+    # sizes are part of the ABI: 35 int32 (+4 pad) + 2 double + 2 int32 + (2 + 8 + 2) int32 + double + (4 text + 2 reserved) int32
     assert C.sizeof(E.pd_config) == 4 * 36 + 16 + 4 * 2 + 4 * 12 + 8 + 4 * 6
     assert C.sizeof(E.pd_sample_args) % 8 == 0
 

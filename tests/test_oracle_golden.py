@@ -158,3 +158,22 @@ def test_vae_decoder_matches_reference(golden_dir, tag, cfg):
     x = O.vae_decode(sd, cfg, W.vae_layout(cfg), g[tag + "_z"])
     assert x.shape == g[tag + "_x"].shape
     assert relerr(x, g[tag + "_x"]) < 5e-5
+
+
+@pytest.mark.parametrize("tag,cfg", [("tiny_b3", W.TINY), ("sd15_b2", W.SD15)])
+def test_clip_text_transformer_matches_transformers(golden_dir, tag, cfg):
+    """Cond stage: fixtures are `transformers.CLIPTextModel(...).last_hidden_state` -- what
+    FrozenCLIPEmbedder.forward returns (ldm/modules/encoders/modules.py:118-128) -- with the seeded weights."""
+    g = np.load(os.path.join(golden_dir, f"clip_{tag}.npz"))
+    sd = W.synth_text_state_dict(cfg)
+    assert len(sd) == 2 + 16 * cfg.text_layers + 2
+    ids = g["ids"]
+    assert np.array_equal(ids, W.synth_token_ids(cfg, int(g["B"])))
+    z = O.clip_text_forward(sd, cfg, ids)
+    if "z" in g:
+        assert relerr(z, g["z"]) < 5e-5
+    else:
+        assert relerr(z.reshape(-1)[::int(g["z_stride"])][:16384], g["z_sub"]) < 5e-5
+    st = g["z_stats"]
+    assert abs(float(np.abs(z).mean()) - st[1]) < 1e-4 * st[1]
+

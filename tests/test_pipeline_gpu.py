@@ -195,3 +195,38 @@ def test_pipeline_with_unipc_scheduler_against_oracle_replay(eng):
 
     ref = O.unipc2_sample(eps_fn, inp["x_T"], sched.alphas_cumprod, ts)
     assert relerr(out, ref) < 5e-4
+
+
+def test_pipeline_from_prompts_with_engine_text_encoder():
+    """String prompts -> tokenizer (caller's) -> pd_text_encode -> loop, all inside one engine (SURVEY N3 + hot path):
+    must equal the same call fed with the oracle's CLIP embeddings of the same token ids."""
+    cfg = W.TINY
+    e = E.Engine(cfg, precision="f32")
+    tsd = W.synth_text_state_dict(cfg)
+    e.load_state_dict({**W.synth_state_dict(cfg), **tsd})
+    vocab = {}
+
+    def toy_tokenizer(prompts):     # BOS, one id per word, EOS padding -- stands in for CLIPTokenizer (BPE files are not available offline)
+        ids = np.full((len(prompts), cfg.context_len), cfg.text_vocab - 1, np.int32)
+        for b, p in enumerate(prompts):
+            ids[b, 0] = cfg.text_vocab - 2
+            for j, wd in enumerate(p.split()[:cfg.context_len - 2]):
+                ids[b, 1 + j] = vocab.setdefault(wd, len(vocab) + 1)
+        return ids
+    pipe = PromptDiffusionPipeline(e, tokenizer=toy_tokenizer)
+    B, hw, S = 2, 64, 4
+    inp = W.synth_inputs(cfg, B, hw // 8, hw // 8, seed=17, unit_range=True)
+    a, b = inp["pair"][:, :3], inp["pair"][:, 3:]
+    prompts = ["a photo of a house, best quality", "a line drawing"]
+    kw = dict(image=inp["query"].transpose(0, 2, 3, 1), image_pair=[a.transpose(0, 2, 3, 1), b.transpose(0, 2, 3, 1)],
+              num_inference_steps=S, guidance_scale=4.0, latents=inp["x_T"], output_type="latent")
+    try:
+        out = pipe(prompt=prompts, negative_prompt="blurry", **kw).images
+        pe = O.clip_text_forward(tsd, cfg, toy_tokenizer(prompts))
+        ne = O.clip_text_forward(tsd, cfg, toy_tokenizer(["blurry"] * B))
+        ref = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, **kw).images
+        assert relerr(out, ref) < 2e-4
+        with pytest.raises(NotImplementedError, match="clip_skip"):
+            pipe(prompt=prompts, clip_skip=1, **kw)
+    finally:
+        e.close()
