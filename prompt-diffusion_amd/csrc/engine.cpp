@@ -546,7 +546,6 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.gn_coef = gn_coef;
     p.gn_silu = gn_silu ? 1 : 0;
     p.diag = opt_diag;
-    p.persist = opt_persist ? 1 : 0;
     // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
     const bool use_patch = opt_patch && conv_patch_tiles(p, f32) >= 192;
     if (gn_coef && !use_patch) {

@@ -228,7 +228,6 @@ struct pd_engine {
     int opt_diag = 0;          // timing diagnostic (wrong results): GEMM operands all read row 0
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
     int opt_dense_tiles = 128;
-    bool opt_persist = true;   // igemm_kernel: persistent tile loop with cross-tile prefetch
     bool opt_gemm8 = false;    // 256 x 256 LDS-DMA tile kernel for big bf16 linear layers
     int opt_gemm8_tiles = 256;
     long long gemm8_launches = 0;

@@ -42,8 +42,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     // register prefetch depth: two K steps ahead (two named staging sets) unless the fp32->bf16 staging
     // path already doubles the A registers
     constexpr int DEPTH = (AF32 || BN > 160 || (BM == 128 && WM * WN == 8)) ? 1 : 2;   // the 16-waves-per-CU shape has 128 VGPRs per wave
-    // persistent tile loop only where one staging set is live (the two-set kernels have no registers to spare for it)
-    constexpr bool PERSIST = DEPTH == 1 && BN > 160;
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int A_ITERS = BM * 8 / NTHREADS;                   // 16-byte chunks per thread per K step
     constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;  // last one masked when it does not divide
@@ -63,55 +61,48 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
 
     // XCD-aware tile order: blocks b and b+8 share an XCD/L2; give each XCD a contiguous run of
     // tiles (n fastest) so neighbouring tiles that share the A rows hit the same L2.
-    // Persistent launches (gridDim.x < tiles): a block walks tiles vtile, vtile + gridDim.x, ... (same XCD: the
-    // grid is a multiple of 8) and requests the next tile's first K step before it runs the epilogue of the current one,
-    // so the load latency and the store drain of consecutive tiles overlap instead of adding up.
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
     const int nblk = mtiles * ntiles;
-    int vtile = blockIdx.x;
-    int bid = 0, bm = 0, bn = 0;
-    auto tile_coords = [&](int v) __attribute__((always_inline)) {
-        const int q = nblk >> 3, r = nblk & 7, x = v & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (v >> 3);
-        bm = bid / ntiles;
-        bn = bid % ntiles;
-    };
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int bm = bid / ntiles, bn = bid % ntiles;
     const int kslice = blockIdx.y;
 
-    // ---- per-thread staging assignment (recomputed per tile)
+    // ---- per-thread staging assignment
     const int chunk = tid & 7;
     const int row0 = tid >> 3;  // + ROWS_PER_IT*i
     int a_pix[A_ITERS];         // CONV: sample * Hin (row base); else unused
     int a_y[A_ITERS], a_x[A_ITERS];
     bool a_ok[A_ITERS];
     size_t a_base[A_ITERS];
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int m = bm * BM + row0 + ROWS_PER_IT * i;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        if constexpr (CONV) {
+            const int b = mm / p.rows_per_sample;
+            const int rem = mm - b * p.rows_per_sample;
+            const int oy = rem / p.Wout;
+            a_pix[i] = b * p.Hin;
+            a_y[i] = oy * p.stride - 1;
+            a_x[i] = (rem - oy * p.Wout) * p.stride - 1;
+            a_base[i] = 0;
+        } else {
+            a_base[i] = (size_t)(p.diag ? 0 : mm) * p.lda;
+            a_pix[i] = a_y[i] = a_x[i] = 0;
+        }
+    }
     const char* w_ptr[B_ITERS];
-    auto setup = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) {
-            const int m = bm * BM + row0 + ROWS_PER_IT * i;
-            a_ok[i] = m < p.M;
-            const int mm = a_ok[i] ? m : 0;
-            if constexpr (CONV) {
-                const int b = mm / p.rows_per_sample;
-                const int rem = mm - b * p.rows_per_sample;
-                const int oy = rem / p.Wout;
-                a_pix[i] = b * p.Hin;
-                a_y[i] = oy * p.stride - 1;
-                a_x[i] = (rem - oy * p.Wout) * p.stride - 1;
-                a_base[i] = 0;
-            } else {
-                a_base[i] = (size_t)(p.diag ? 0 : mm) * p.lda;
-                a_pix[i] = a_y[i] = a_x[i] = 0;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            int n = bn * BN + row0 + ROWS_PER_IT * i;
-            n = n < p.N ? n : p.N - 1;  // clamp: columns >= N are never stored
-            w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(p.diag ? 0 : n) * (p.ldw ? p.ldw : p.Kpad) + chunk * VEC) * EB;
-        }
-    };
+    for (int i = 0; i < B_ITERS; ++i) {
+        int n = bn * BN + row0 + ROWS_PER_IT * i;
+        n = n < p.N ? n : p.N - 1;  // clamp: columns >= N are never stored
+        w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(p.diag ? 0 : n) * (p.ldw ? p.ldw : p.Kpad) + chunk * VEC) * EB;
+    }
 
     const int ktiles_all = p.Kpad / BKE;
     int kt0 = 0, kt1 = ktiles_all;
@@ -219,6 +210,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     };
 
     f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     const int fr = lane & 15, fq = lane >> 4;
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const char* sa = smem + buf * (BM + BN) * BKB;
@@ -238,16 +234,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    tile_coords(vtile);
-    setup();
-    if (kt0 < kt1) gload(S0{}, kt0);
-    for (;;) {   // tiles of this block
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (DEPTH == 1) {
-        if (kt0 < kt1) lstore(S0{}, 0);
+        if (kt0 < kt1) {
+            gload(S0{}, kt0);
+            lstore(S0{}, 0);
+        }
         __syncthreads();
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
@@ -261,6 +252,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
         // tile kt is computed from LDS buffer (kt-kt0)&1 while tile kt+1 waits in the other register set and
         // tile kt+2 is being requested: every global load has two K steps of MFMAs to land
         if (kt0 < kt1) {
+            gload(S0{}, kt0);
             lstore(S0{}, 0);
             if (kt0 + 1 < kt1) gload(S1{}, kt0 + 1);
         }
@@ -277,19 +269,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             __syncthreads();
         }
     }
-    // every wave is past its last LDS read (closing barrier): the next tile may be requested now
-    const int cbm = bm, cbn = bn, cbid = bid;
-    bool more_tiles = false;
-    if constexpr (PERSIST) {
-        const int nv = vtile + (int)gridDim.x;
-        more_tiles = nv < nblk;
-        if (more_tiles) {
-            vtile = nv;
-            tile_coords(nv);
-            setup();
-            if (kt0 < kt1) gload(S0{}, kt0);
-        }
-    }
 
     // ---- epilogue: lane holds channels n..n+3 (rows of the swapped MFMA) of pixel m
     if (p.splitk > 1) {
@@ -297,11 +276,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             float* slab = reinterpret_cast<float*>(p.slab) + (size_t)kslice * p.M * p.N;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int gm = cbm * BM + wm * WTM + m * 16 + fr;
+                const int gm = bm * BM + wm * WTM + m * 16 + fr;
                 if (gm >= p.M) continue;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const int gn = cbn * BN + wn * WTN + n * 16 + fq * 4;
+                    const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
                     if (gn >= p.N) continue;
                     *reinterpret_cast<f32x4*>(slab + (size_t)gm * p.N + gn) = acc[n][m];
                 }
@@ -318,10 +297,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             constexpr int SC1 = 16;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int gm = cbm * BM + wm * WTM + m * 16 + fr;
+                const int gm = bm * BM + wm * WTM + m * 16 + fr;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const int gn = cbn * BN + wn * WTN + n * 16 + fq * 4;
+                    const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
                     if (gm >= p.M || gn >= p.N) continue;
                     const unsigned off = (unsigned)(((kslice * p.M + gm) * p.N + gn) * 4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[n][m]), rs, off, 0, SC1);
@@ -331,9 +310,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             __syncthreads();
             int* s_last = reinterpret_cast<int*>(smem);
             if (tid == 0) {
-                const int old = __hip_atomic_fetch_add(p.tile_cnt + cbid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int old = __hip_atomic_fetch_add(p.tile_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int last = old == p.splitk - 1;
-                if (last) __hip_atomic_store(p.tile_cnt + cbid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next GEMM
+                if (last) __hip_atomic_store(p.tile_cnt + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next GEMM
                 *s_last = last;
             }
             __syncthreads();
@@ -342,10 +321,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             for (int s = 0; s < p.splitk; ++s) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const int gm = cbm * BM + wm * WTM + m * 16 + fr;
+                    const int gm = bm * BM + wm * WTM + m * 16 + fr;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const int gn = cbn * BN + wn * WTN + n * 16 + fq * 4;
+                        const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
                         if (gm >= p.M || gn >= p.N) continue;
                         const unsigned off = (unsigned)(((s * p.M + gm) * p.N + gn) * 4);
                         const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, SC1));
@@ -359,19 +338,19 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int gm = cbm * BM + wm * WTM + m * 16 + fr;
+        const int gm = bm * BM + wm * WTM + m * 16 + fr;
         if (gm >= p.M) continue;
         const int sample = gm / p.rows_per_sample;
         const int tok = gm - sample * p.rows_per_sample;
         if (p.act == 2) {
             // GEGLU: virtual columns [0,80) of this tile are x, [80,160) the gate (weights interleaved at load)
-            if constexpr (NT % 10 == 0) {   // a wave owns whole 160-column blocks
+            if constexpr (NT % 10 == 0 && WN == 1) {
 #pragma unroll
                 for (int sb = 0; sb < NT / 10; ++sb) {   // 160-column sub-blocks: [80 x | 80 gate]
 #pragma unroll
                     for (int n = 0; n < 5; ++n) {
-                        const int vn = cbn * BN + wn * WTN + sb * 160 + n * 16 + fq * 4;
-                        const int on = ((cbn * BN + wn * WTN) / 160 + sb) * 80 + n * 16 + fq * 4;
+                        const int vn = bn * BN + sb * 160 + n * 16 + fq * 4;
+                        const int on = (bn * (BN / 160) + sb) * 80 + n * 16 + fq * 4;
                         if (on >= p.Nout) continue;
                         f32x4 x = acc[sb * 10 + n][m], g = acc[sb * 10 + n + 5][m];
                         if (p.bias) {
@@ -389,13 +368,11 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int gn = cbn * BN + wn * WTN + n * 16 + fq * 4;
+            const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
             if (gn >= p.N) continue;
             epilogue4(p, gm, gn, sample, tok, acc[n][m]);
         }
     }
-    if (!more_tiles) break;
-    }   // tiles
 }
 
 // sums the split-K slabs in slice order and applies the epilogue; one thread per 4 channels
@@ -427,18 +404,6 @@ int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     }
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
     dim3 grid(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1);
-    if (p.persist && p.splitk <= 1 && BN > 160) {
-        // persistent launch: one block per resident slot, each walking several tiles
-        static int slots = 0;
-        if (!slots) {
-            int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, NTHREADS, SMEM_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-            slots = per_cu * (cus / 8 * 8);
-        }
-        if ((int)grid.x > slots) grid.x = slots;
-    }
     hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, s, p);
     if (hipGetLastError() != hipSuccess) return 1;
     if (mid) (void)hipEventRecord(mid, s);   // profiling: end of the contraction kernel proper

@@ -103,7 +103,6 @@ struct GemmParams {
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;
     int ldw;              // weight row stride in elements (0: Kpad) -- lets a device activation act as the W operand
-    int persist;          // igemm_kernel: launch one block per resident slot and walk the tiles (cross-tile prefetch)
     int diag;             // timing diagnostic: every tile row reads row 0 (operands served from L1); results are wrong
 };
 

@@ -83,7 +83,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("PDENGINE_LIB") or LIB_PATH    # PDENGINE_LIB: A/B another build of the library
     if not os.path.exists(p):
         raise PdError(f"{p} not found: build it with `make -C {_CSRC}` (or __graft_entry__.build()); "
                       "pdengine has no CPU fallback")

@@ -139,30 +139,6 @@ def test_geglu(eng, M, C):
     assert relerr(eng.op_linear(x, w, b, geglu=True), a * O.gelu(gate)) < TOL[eng.prec]
 
 
-def test_persistent_tile_loop_matches_one_tile_per_block(eng):
-    """256 x 320 tiles with more tiles (56 x 8 = 448) than resident blocks: each block walks several tiles and requests
-    the next tile's first K step before the epilogue of the current one (option 'persist').  Same arithmetic per
-    tile, so the result must be bit-identical to the one-tile-per-block launch, for the plain and the GEGLU epilogue."""
-    g = rng(13)
-    M, K, N = 14336, 320, 2560
-    x = g.standard_normal((M, K), dtype=np.float32)
-    w = (g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
-    b = g.standard_normal(N, dtype=np.float32) * 0.1
-    try:
-        eng.set_option("persist", 0)
-        y0 = eng.op_linear(x, w, b)
-        g0 = eng.op_linear(x, w, b, geglu=True)
-        eng.set_option("persist", 1)
-        assert np.array_equal(eng.op_linear(x, w, b), y0)
-        assert np.array_equal(eng.op_linear(x, w, b, geglu=True), g0)
-    finally:
-        eng.set_option("persist", 1)
-    h = O.linear(x, w, b)
-    assert relerr(y0, h) < TOL[eng.prec]
-    a, gate = np.split(h, 2, axis=-1)
-    assert relerr(g0, a * O.gelu(gate)) < TOL[eng.prec]
-
-
 @pytest.mark.parametrize("B,C,H,W,eps,silu", [(2, 64, 8, 8, 1e-5, True), (3, 320, 16, 16, 1e-6, False),
                                                (1, 960, 4, 4, 1e-5, True), (2, 128, 5, 3, 1e-5, True),
                                                (1, 2560, 8, 8, 1e-5, True)])

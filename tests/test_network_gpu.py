@@ -57,7 +57,10 @@ def test_param_registry_matches_reference_checkpoint(golden_dir):
     names = e.param_names()
     assert names[:len(want)] == want
     # the optional first-stage decoder follows, under the checkpoint's first_stage_model.* names
-    assert names[len(want):] == [(n, tuple(s)) for n, s, _ in W.vae_spec(W.SD15)]
+    nv = len(W.vae_spec(W.SD15))
+    assert names[len(want):len(want) + nv] == [(n, tuple(s)) for n, s, _ in W.vae_spec(W.SD15)]
+    # ... and the cond-stage text transformer, under cond_stage_model.transformer.text_model.* in module order
+    assert names[len(want) + nv:] == [(n, tuple(s)) for n, s, _ in W.text_spec(W.SD15)]
     e.close()
 
 
