@@ -172,7 +172,16 @@ int pd_make_schedule(pd_engine* e, int32_t steps, float eta, int64_t* timesteps,
 /* instrumentation */
 int pd_synchronize(pd_engine* e);
 void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches on */
-int pd_set_option(pd_engine* e, const char* key, int64_t value); /* "use_graph", "verbose" ... */
+/* Tuning / instrumentation knobs (defaults are the measured best; tests and tools/ flip them for A/B runs):
+ *   "verbose", "profile" (HIP events around every contraction launch, see pd_profile_read),
+ *   "two_streams" (ControlNet on a second stream beside the UNet encoder, default 1),
+ *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "gn_fuse" (GroupNorm applied while the patch is staged, 0),
+ *   "big_tile" / "wide_tile" (256x160 / 256x320 GEMM tiles, 1), "dense_k" / "dense_tiles" (8-wave unsplit tile for
+ *   linear layers with at most that many K steps, 40 / 128), "splitk_tiles" (split K below this many tiles, 384),
+ *   "splitk_fused" (in-kernel split-K finalize, 0), "gemm8" / "gemm8_tiles" (256x256 LDS-DMA GEMM, 0 / 256),
+ *   "attn_legacy" (single-buffered attention kernel, 0), "diag" (timing diagnostic: GEMM operands all read row 0,
+ *   results are WRONG, 0). */
+int pd_set_option(pd_engine* e, const char* key, int64_t value);
 int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches", "steps", "gemm8_launches" */
 /* Per-launch timing: while option "profile" is 1 the engine brackets every contraction launch with HIP
  * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel on a conv1x1/linear,
