@@ -109,7 +109,7 @@ def main():
     def one_pass():
         lat = eng.ddim_sample(**kw)          # blocking: stream-synchronised on return
         if world > 1:
-            lat = all_gather_latents(lat)    # the path's only exchange: final latents over RCCL/xGMI
+            lat = all_gather_latents(lat, sizes=[B] * world)    # the path's only exchange: ONE all-gather of the final latents over RCCL/xGMI
         return lat
 
     def barrier():

@@ -27,21 +27,25 @@ def shard_batch(inputs: Dict[str, "np.ndarray"], rank: int, world: int) -> Dict[
     return {k: (v[lo:hi] if v is not None else None) for k, v in inputs.items()}
 
 
-def all_gather_latents(latents, group=None):
+def all_gather_latents(latents, group=None, sizes=None):
     """Gather [b_r, C, h, w] shards from every rank into [sum b_r, C, h, w] (rank order = batch order).
 
-    Equal shards use one all_gather_into_tensor (a single direct RCCL all-gather: <= 4 MB total at
-    bs=64, latency-bound); ragged shards are padded to the largest and trimmed."""
+    `sizes`: the per-rank shard sizes when the caller knows them (shard_range is deterministic) -- then this is exactly
+    ONE collective, a direct RCCL all_gather_into_tensor (<= 4 MB total at bs=64, latency-bound).  Without it the sizes
+    are exchanged first.  Ragged shards are padded to the largest and trimmed."""
     import torch
     import torch.distributed as dist
     t = latents if isinstance(latents, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(latents))
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
     world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+        got = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(got, n, group=group)
+        sizes = [int(s.item()) for s in got]
+    elif len(sizes) != world or sizes[dist.get_rank(group)] != t.shape[0]:
+        raise ValueError("sizes must list every rank's shard size")
     mx = max(sizes)
     if t.shape[0] < mx:
         pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)

@@ -29,6 +29,10 @@ def _worker(rank, world, port, n, q):
     mine = shard_batch({"x": full}, rank, world)["x"]
     # stand-in for the per-rank sampling result: a rank-independent function of the shard
     got = all_gather_latents(torch.from_numpy(mine * 2.0 + 1.0))
+    # with the shard sizes known up front (shard_range is deterministic) it is a single collective
+    known = [b - a for a, b in (shard_range(n, r, world) for r in range(world))]
+    got2 = all_gather_latents(torch.from_numpy(mine * 2.0 + 1.0), sizes=known)
+    assert torch.equal(got, got2)
     q.put((rank, got.numpy()))
     dist.barrier()
     dist.destroy_process_group()
