@@ -175,6 +175,7 @@ void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches o
 /* Tuning / instrumentation knobs (defaults are the measured best; tests and tools/ flip them for A/B runs):
  *   "verbose", "profile" (HIP events around every contraction launch, see pd_profile_read),
  *   "two_streams" (ControlNet on a second stream beside the UNet encoder, default 1),
+ *   "graph" (pd_ddim_sample captures its step loop in a hipGraph and replays it on later calls with equal arguments, 0),
  *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "gn_fuse" (GroupNorm applied while the patch is staged, 0),
  *   "big_tile" / "wide_tile" (256x160 / 256x320 GEMM tiles, 1), "dense_k" / "dense_tiles" (8-wave unsplit tile for
  *   linear layers with at most that many K steps, 40 / 128), "splitk_tiles" (split K below this many tiles, 384),

@@ -206,6 +206,11 @@ struct pd_engine {
     NetW unet, cnet;
     VaeW vae;
     TextW text;
+    // captured step loops (option "graph"): key = everything a step's kernel arguments depend on
+    struct GraphEntry { uint64_t key; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    void clear_graphs();
+    int run_steps_graph();
     int reg_group = 0;
     std::vector<void*> owned;  // device allocations (weights)
     size_t weight_bytes = 0;
@@ -228,6 +233,7 @@ struct pd_engine {
     int opt_diag = 0;          // timing diagnostic (wrong results): GEMM operands all read row 0
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
     int opt_dense_tiles = 128;
+    bool opt_graph = false;    // pd_ddim_sample: capture the step loop in a hipGraph and replay it on later calls with the same arguments
     bool opt_gemm8 = false;    // 256 x 256 LDS-DMA tile kernel for big bf16 linear layers
     int opt_gemm8_tiles = 256;
     long long gemm8_launches = 0;

@@ -252,6 +252,7 @@ int pd_engine::ensure_arena(int Bf, int h, int w, int rows, bool per_step) {
         return 0;
     };
     if (need > arena.cap || need2 > arena2.cap) {
+        clear_graphs();   // captured loops point into the old workspaces
         HIP_OK(hipStreamSynchronize(stream));
         if (stream2) HIP_OK(hipStreamSynchronize(stream2));
         PD_TRY(grow(arena, need, "main"));
@@ -337,6 +338,66 @@ int pd_engine::step(int i) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------ captured step loop
+// The S steps of a call differ only in kernel ARGUMENTS (time-embedding row, DDIM coefficients, control scales, noise
+// slice); every buffer they touch is carved out of the two workspaces in a deterministic order by begin().  So the
+// whole loop of a call -- ControlNet on the second stream included, through the fork / join events -- is captured once
+// into a hipGraph and replayed by later calls whose arguments hash to the same key.  Pays where the loop is
+// launch-bound on the host (small batches); the inputs are staged by begin() outside the graph.
+void pd_engine::clear_graphs() {
+    for (auto& g : graphs) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
+    graphs.clear();
+}
+
+static inline void hash_mix(uint64_t& h, const void* p, size_t n) {
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+}
+
+int pd_engine::run_steps_graph() {
+    const pd_sample_args& a = ses.a;
+    uint64_t key = 1469598103934665603ull;
+    const int32_t ints[] = {a.batch, a.h, a.w, a.steps, a.use_cfg, a.guess_mode, a.only_mid_control, ses.noise ? 1 : 0,
+                            ses.per_step ? 1 : 0, opt_two_streams ? 1 : 0, ses.S};
+    const float flts[] = {a.eta, a.cfg_scale, a.temperature};
+    const void* ptrs[] = {arena.base, arena2.base, ses.x_state, ses.per_step};
+    hash_mix(key, ints, sizeof(ints));
+    hash_mix(key, flts, sizeof(flts));
+    hash_mix(key, ptrs, sizeof(ptrs));
+    hash_mix(key, ses.scales_step.data(), ses.scales_step.size() * sizeof(float));
+    for (auto& g : graphs)
+        if (g.key == key) {
+            HIP_OK(hipGraphLaunch(g.exec, stream));
+            return 0;
+        }
+    GraphEntry ge{key, nullptr, nullptr};
+    if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        for (int i = 0; i < ses.S; ++i) PD_TRY(step(i));   // capture unavailable: run eagerly
+        return 0;
+    }
+    int rc = 0;
+    for (int i = 0; i < ses.S && !rc; ++i) rc = step(i);
+    const hipError_t ec = hipStreamEndCapture(stream, &ge.graph);
+    if (rc || ec != hipSuccess || !ge.graph) {
+        if (ge.graph) hipGraphDestroy(ge.graph);
+        if (!rc) pd_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+        return 1;
+    }
+    if (hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0) != hipSuccess) {
+        hipGraphDestroy(ge.graph);
+        pd_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(hipGetLastError()));
+        return 1;
+    }
+    if (graphs.size() >= 8) clear_graphs();
+    graphs.push_back(ge);
+    HIP_OK(hipGraphLaunch(ge.exec, stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -377,6 +438,7 @@ void pd_engine_destroy(pd_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    e->clear_graphs();
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -570,7 +632,11 @@ int pd_sample_end(pd_engine* e) {
 int pd_ddim_sample(pd_engine* e, const pd_sample_args* args, int32_t mem_out, float* latents_out, float* per_step_out) {
     if (!e || !latents_out) { pd_set_error("null argument"); return 1; }
     PD_TRY(e->begin(args, per_step_out != nullptr));
-    for (int i = 0; i < e->ses.S; ++i) PD_TRY(e->step(i));
+    if (e->opt_graph && !e->profiling) {
+        PD_TRY(e->run_steps_graph());
+    } else {
+        for (int i = 0; i < e->ses.S; ++i) PD_TRY(e->step(i));
+    }
     PD_TRY(pd_sample_get(e, PD_GET_LATENTS, mem_out, latents_out));
     if (per_step_out) {
         const size_t n = (size_t)(e->ses.S + 1) * args->batch * e->cfg.in_channels * args->h * args->w;
@@ -591,6 +657,8 @@ void* pd_stream(pd_engine* e) { return e ? (void*)e->stream : nullptr; }
 int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!e || !key) { pd_set_error("null argument"); return 1; }
     if (!strcmp(key, "verbose")) { e->verbose = (int)value; return 0; }
+    e->clear_graphs();   // every other knob changes what a step launches
+    if (!strcmp(key, "graph")) { e->opt_graph = value != 0; return 0; }
     if (!strcmp(key, "conv_patch")) { e->opt_patch = value != 0; return 0; }
     if (!strcmp(key, "splitk_fused")) { e->opt_splitk_fused = value != 0; return 0; }
     if (!strcmp(key, "splitk_tiles")) { e->opt_splitk_tiles = (int)value; return 0; }

@@ -122,6 +122,7 @@ extern "C" int pd_text_encode(pd_engine* e, const int32_t* ids, int32_t B, int32
     if (!r && need > e->arena.cap) {
         hipStreamSynchronize(e->stream);
         if (e->stream2) hipStreamSynchronize(e->stream2);
+        e->clear_graphs();   // captured step loops point into this workspace
         if (e->arena.base) hipFree(e->arena.base);
         e->arena.base = nullptr; e->arena.cap = 0;
         void* p = nullptr;

@@ -192,6 +192,7 @@ extern "C" int pd_vae_decode(pd_engine* e, const float* latents, int32_t B, int3
     if (!r && need > e->arena.cap) {
         hipStreamSynchronize(e->stream);
         if (e->stream2) hipStreamSynchronize(e->stream2);
+        e->clear_graphs();   // captured step loops point into this workspace
         if (e->arena.base) hipFree(e->arena.base);
         e->arena.base = nullptr; e->arena.cap = 0;
         void* p = nullptr;

@@ -231,3 +231,27 @@ def test_sd15_config1(golden_dir, prec, tol_step, tol_eps):
     print(f"sd15 {prec} per-step latent relerr:", ["%.2e" % v for v in errs])
     assert max(errs) < tol_step
     e.close()
+
+
+def test_graph_replay_is_bit_identical(tiny_f32):
+    """Option 'graph': the step loop of pd_ddim_sample captured in a hipGraph (both streams, fork/join events) and
+    replayed on later calls with the same arguments.  Capture, replay, replay-with-new-inputs and a changed argument
+    (new capture) must all equal the eager loop bit for bit."""
+    e = tiny_f32
+    inp = W.synth_inputs(W.TINY, 2, 16, 16, seed=3)
+    inp2 = W.synth_inputs(W.TINY, 2, 16, 16, seed=4)
+    kw = lambda i, s=5.0: dict(x_T=i["x_T"], ctx_cond=i["ctx_cond"], ctx_uncond=i["ctx_uncond"], pair=i["pair"], query=i["query"],
+                               steps=4, cfg_scale=s)
+    eager1, eager2, eager3 = e.ddim_sample(**kw(inp)), e.ddim_sample(**kw(inp2)), e.ddim_sample(**kw(inp, 3.0))
+    try:
+        e.set_option("graph", 1)
+        np.testing.assert_array_equal(e.ddim_sample(**kw(inp)), eager1)     # capture + launch
+        np.testing.assert_array_equal(e.ddim_sample(**kw(inp)), eager1)     # replay
+        np.testing.assert_array_equal(e.ddim_sample(**kw(inp2)), eager2)    # replay, other inputs (staged by begin())
+        np.testing.assert_array_equal(e.ddim_sample(**kw(inp, 3.0)), eager3)   # other guidance scale: new graph
+        np.testing.assert_array_equal(e.ddim_sample(**kw(inp)), eager1)     # back to the first graph
+        got, inter = e.ddim_sample(return_intermediates=True, **kw(inp))
+        np.testing.assert_array_equal(got, eager1)
+        np.testing.assert_array_equal(inter[-1], eager1)
+    finally:
+        e.set_option("graph", 0)
