@@ -177,6 +177,7 @@ void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches o
  *   "two_streams" (ControlNet on a second stream beside the UNet encoder, default 1),
  *   "graph" (pd_ddim_sample captures its step loop in a hipGraph and replays it on later calls with equal arguments, 0),
  *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "gn_fuse" (GroupNorm applied while the patch is staged, 0),
+ *   "gn_single" (single-kernel LDS-slab GroupNorm where a sample's group bundle fits, 1),
  *   "big_tile" / "wide_tile" (256x160 / 256x320 GEMM tiles, 1), "dense_k" / "dense_tiles" (8-wave unsplit tile for
  *   linear layers with at most that many K steps, 40 / 128), "splitk_tiles" (split K below this many tiles, 384),
  *   "splitk_fused" (in-kernel split-K finalize, 0), "gemm8" / "gemm8_tiles" (256x256 LDS-DMA GEMM, 0 / 256),

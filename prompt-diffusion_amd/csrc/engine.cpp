@@ -637,6 +637,15 @@ int pd_engine::gn_stats(const Act& x, int& nchunk) {
 }
 
 int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu) {
+    if (opt_gn_single && gn_fused_bundle(x.dt, x.H * x.W, x.C, 32)) {   // slab fits in LDS: one kernel, one read
+        if (arena.dry) return 0;
+        ++launches;
+        if (launch_gn_fused(x.p, x.dt, y.p, y.dt, g, b, x.B, x.H * x.W, x.C, 32, eps, silu ? 1 : 0, stream)) {
+            pd_set_error("groupnorm (single kernel) launch failed (C=%d)", x.C);
+            return 1;
+        }
+        return 0;
+    }
     int nchunk = 1;
     PD_TRY(gn_stats(x, nchunk));
     if (arena.dry) return 0;

@@ -233,6 +233,7 @@ struct pd_engine {
     int opt_diag = 0;          // timing diagnostic (wrong results): GEMM operands all read row 0
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
     int opt_dense_tiles = 128;
+    bool opt_gn_single = true; // GroupNorm as one LDS-slab kernel where a sample's group bundle fits (32x32 and below)
     bool opt_graph = false;    // pd_ddim_sample: capture the step loop in a hipGraph and replay it on later calls with the same arguments
     bool opt_gemm8 = false;    // 256 x 256 LDS-DMA tile kernel for big bf16 linear layers
     int opt_gemm8_tiles = 256;

@@ -168,6 +168,132 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
     }
 }
 
+// Single-kernel GroupNorm for the levels where one sample's slab of a few groups fits in LDS (32x32 and below):
+// a block owns (sample, bundle of groups whose channels align to 16-byte vectors: lcm(channels per group, VEC)),
+// loads the HW x bundle slab once into LDS, reduces the statistics in a fixed order (deterministic), then
+// normalises out of LDS.  One read + one write of the tensor and one launch instead of two reads + one write in two.
+constexpr int GNF_THREADS = 240;   // divisible by 5, 10, 15 (vectors per pixel of the bundles that occur)
+
+template <bool XF32, bool YF32>
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int HW, int C, int groups, int BC, float eps, int do_silu) {
+    constexpr int VEC = XF32 ? 4 : 8;
+    constexpr int EX = XF32 ? 4 : 2;
+    extern __shared__ __attribute__((aligned(16))) char slab[];   // [HW][BC] raw input, then [GNF_THREADS][4][2] doubles
+    const int nb = C / BC;
+    // consecutive bundles of a sample (which share 128-byte lines) on the same XCD: blocks b and b+8 share an L2
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x, q = total >> 3, r = total & 7, xk = bid & 7;
+        bid = (xk < r ? xk * (q + 1) : r * (q + 1) + (xk - r) * q) + (bid >> 3);
+    }
+    const int b = bid / nb, bundle = bid - b * nb;
+    const int tid = threadIdx.x;
+    const int nvec = BC / VEC;              // vectors per pixel in this bundle
+    const int v = tid % nvec, pr = tid / nvec;
+    const int rows_par = GNF_THREADS / nvec;
+    const int cpg = C / groups, gpb = BC / cpg;   // groups per bundle (<= 4)
+    const int c0 = bundle * BC + v * VEC;         // first channel of this thread's vector
+    double* red = reinterpret_cast<double*>(slab + (size_t)HW * BC * EX);
+    const char* xb = reinterpret_cast<const char*>(x) + ((size_t)b * HW * C + c0) * EX;
+
+    // ---- pass 1: global -> LDS, per-thread per-channel sums (short fp32 runs flushed into fp64)
+    double ds[VEC], dq[VEC];
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { ds[j] = 0.0; dq[j] = 0.0; s[j] = 0.f; q[j] = 0.f; }
+    int cnt = 0;
+    for (int p = pr; p < HW; p += rows_par) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C * EX);
+        *reinterpret_cast<uint4*>(slab + ((size_t)p * nvec + v) * 16) = raw;
+        float f[VEC];
+        if constexpr (XF32) {
+            const float* t = reinterpret_cast<const float*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = t[j];
+        } else {
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+        if (++cnt == 16) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { ds[j] += s[j]; dq[j] += q[j]; s[j] = 0.f; q[j] = 0.f; }
+            cnt = 0;
+        }
+    }
+    // this thread's contribution to each group of the bundle
+    double gs[4] = {0.0, 0.0, 0.0, 0.0}, gq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int g = (v * VEC + j) / cpg;
+        const double a = ds[j] + s[j], bq = dq[j] + q[j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k == g) { gs[k] += a; gq[k] += bq; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[(tid * 4 + k) * 2] = gs[k]; red[(tid * 4 + k) * 2 + 1] = gq[k]; }
+    __syncthreads();
+    __shared__ float s_mean[4], s_rstd[4];
+    if (tid < gpb) {   // fixed summation order: bit-reproducible
+        double S = 0.0, Q = 0.0;
+        for (int t = 0; t < GNF_THREADS; ++t) { S += red[(t * 4 + tid) * 2]; Q += red[(t * 4 + tid) * 2 + 1]; }
+        const double n = (double)HW * (double)cpg;
+        const double mean = S / n;
+        double var = Q / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    // ---- pass 2: LDS -> normalise -> global
+    float ka[VEC], kb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int g = (v * VEC + j) / cpg;
+        ka[j] = s_rstd[g] * gamma[c0 + j];
+        kb[j] = beta[c0 + j] - s_mean[g] * ka[j];
+    }
+    char* yb = reinterpret_cast<char*>(y) + ((size_t)b * HW * C + c0) * (YF32 ? 4 : 2);
+    for (int p = pr; p < HW; p += rows_par) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(slab + ((size_t)p * nvec + v) * 16);
+        float f[VEC];
+        if constexpr (XF32) {
+            const float* t = reinterpret_cast<const float*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = t[j];
+        } else {
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float r = fmaf(f[j], ka[j], kb[j]);
+            f[j] = do_silu ? silu_f(r) : r;
+        }
+        if constexpr (YF32) {
+            float* o = reinterpret_cast<float*>(yb + (size_t)p * C * 4);
+#pragma unroll
+            for (int h = 0; h < VEC / 4; ++h) *reinterpret_cast<f32x4*>(o + 4 * h) = f32x4{f[4 * h], f[4 * h + 1], f[4 * h + 2], f[4 * h + 3]};
+        } else {
+            uint16_t* o = reinterpret_cast<uint16_t*>(yb + (size_t)p * C * 2);
+            if constexpr (VEC == 8) {
+                uint4 u;
+                u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
+                *reinterpret_cast<uint4*>(o) = u;
+            } else {
+                uint2 u;
+                u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]);
+                *reinterpret_cast<uint2*>(o) = u;
+            }
+        }
+    }
+}
+
 // Folds the GroupNorm statistics and affine parameters into per-(sample, channel) coefficients
 // coef[b][c] = {a, b} with y = x * a + b, consumed by the conv kernels that normalise while staging.
 __global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
@@ -276,6 +402,41 @@ int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* pa
     else if (y_dt == DT_F32) GN_AP(false, true);
     else GN_AP(false, false);
 #undef GN_AP
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// bundle width (channels) for gn_fused_kernel, or 0 when the shape is not eligible (slab beyond the LDS budget)
+int gn_fused_bundle(int x_dt, int HW, int C, int groups) {
+    const int VEC = x_dt == DT_F32 ? 4 : 8, EX = x_dt == DT_F32 ? 4 : 2;
+    if (C % groups) return 0;
+    const int cpg = C / groups;
+    int BC = cpg;
+    while (BC % VEC) BC += cpg;           // lcm(cpg, VEC)
+    if (C % BC || BC / cpg > 4 || GNF_THREADS % (BC / VEC)) return 0;
+    const size_t bytes = (size_t)HW * BC * EX + GNF_THREADS * 4 * 2 * sizeof(double);
+    return bytes <= 100 * 1024 ? BC : 0;
+}
+
+int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta, int B, int HW, int C, int groups,
+                    float eps, int do_silu, hipStream_t s) {
+    const int BC = gn_fused_bundle(x_dt, HW, C, groups);
+    if (!BC) return 1;
+    const int EX = x_dt == DT_F32 ? 4 : 2;
+    const size_t smem = (size_t)HW * BC * EX + GNF_THREADS * 4 * 2 * sizeof(double);
+    const dim3 grid(B * (C / BC));
+#define GNF(XF, YF)                                                                                                        \
+    do {                                                                                                                   \
+        static bool attr_done = false;                                                                                     \
+        auto kfn = gn_fused_kernel<XF, YF>;                                                                                \
+        if (!attr_done) {                                                                                                  \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024) != hipSuccess) return 1; \
+            attr_done = true;                                                                                              \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kfn, grid, dim3(GNF_THREADS), smem, s, x, y, gamma, beta, HW, C, groups, BC, eps, do_silu);      \
+    } while (0)
+    const bool xf = x_dt == DT_F32, yf = y_dt == DT_F32;
+    if (xf && yf) GNF(true, true); else if (xf) GNF(true, false); else if (yf) GNF(false, true); else GNF(false, false);
+#undef GNF
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -129,6 +129,9 @@ int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s);
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
                     const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s);
+int gn_fused_bundle(int x_dt, int HW, int C, int groups);   // norm.hip: > 0 when the single-kernel GroupNorm applies
+int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta, int B, int HW, int C, int groups,
+                    float eps, int do_silu, hipStream_t s);
 int launch_gn_coef(const double* partial, const float* gamma, const float* beta, float* coef, int B, int HW, int C, int groups,
                    int nchunk, float eps, hipStream_t s);
 int launch_layernorm(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta,

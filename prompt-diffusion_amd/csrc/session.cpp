@@ -658,6 +658,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!e || !key) { pd_set_error("null argument"); return 1; }
     if (!strcmp(key, "verbose")) { e->verbose = (int)value; return 0; }
     e->clear_graphs();   // every other knob changes what a step launches
+    if (!strcmp(key, "gn_single")) { e->opt_gn_single = value != 0; return 0; }
     if (!strcmp(key, "graph")) { e->opt_graph = value != 0; return 0; }
     if (!strcmp(key, "conv_patch")) { e->opt_patch = value != 0; return 0; }
     if (!strcmp(key, "splitk_fused")) { e->opt_splitk_fused = value != 0; return 0; }
