@@ -172,7 +172,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
 // a block owns (sample, bundle of groups whose channels align to 16-byte vectors: lcm(channels per group, VEC)),
 // loads the HW x bundle slab once into LDS, reduces the statistics in a fixed order (deterministic), then
 // normalises out of LDS.  One read + one write of the tensor and one launch instead of two reads + one write in two.
-constexpr int GNF_THREADS = 240;   // divisible by 5, 10, 15 (vectors per pixel of the bundles that occur)
+constexpr int GNF_THREADS = 960;   // 15 waves; divisible by 5, 10, 15 (vectors per pixel of the bundles that occur)
 
 template <bool XF32, bool YF32>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __restrict__ x, void* __restrict__ y,
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __res
                                                                 int HW, int C, int groups, int BC, float eps, int do_silu) {
     constexpr int VEC = XF32 ? 4 : 8;
     constexpr int EX = XF32 ? 4 : 2;
-    extern __shared__ __attribute__((aligned(16))) char slab[];   // [HW][BC] raw input, then [GNF_THREADS][4][2] doubles
+    extern __shared__ __attribute__((aligned(16))) char slab[];   // [HW][BC] raw input, then [waves][4][2] doubles
     const int nb = C / BC;
     // consecutive bundles of a sample (which share 128-byte lines) on the same XCD: blocks b and b+8 share an L2
     int bid = blockIdx.x;
@@ -234,13 +234,20 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __res
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (k == g) { gs[k] += a; gq[k] += bq; }
     }
+    // wave butterfly (fixed order), then the 15 wave partials summed in wave order: bit-reproducible
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { red[(tid * 4 + k) * 2] = gs[k]; red[(tid * 4 + k) * 2 + 1] = gq[k]; }
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { gs[k] += __shfl_xor(gs[k], o); gq[k] += __shfl_xor(gq[k], o); }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[((tid >> 6) * 4 + k) * 2] = gs[k]; red[((tid >> 6) * 4 + k) * 2 + 1] = gq[k]; }
+    }
     __syncthreads();
     __shared__ float s_mean[4], s_rstd[4];
-    if (tid < gpb) {   // fixed summation order: bit-reproducible
+    if (tid < gpb) {
         double S = 0.0, Q = 0.0;
-        for (int t = 0; t < GNF_THREADS; ++t) { S += red[(t * 4 + tid) * 2]; Q += red[(t * 4 + tid) * 2 + 1]; }
+        for (int t = 0; t < GNF_THREADS / 64; ++t) { S += red[(t * 4 + tid) * 2]; Q += red[(t * 4 + tid) * 2 + 1]; }
         const double n = (double)HW * (double)cpg;
         const double mean = S / n;
         double var = Q / n - mean * mean;
@@ -413,7 +420,7 @@ int gn_fused_bundle(int x_dt, int HW, int C, int groups) {
     int BC = cpg;
     while (BC % VEC) BC += cpg;           // lcm(cpg, VEC)
     if (C % BC || BC / cpg > 4 || GNF_THREADS % (BC / VEC)) return 0;
-    const size_t bytes = (size_t)HW * BC * EX + GNF_THREADS * 4 * 2 * sizeof(double);
+    const size_t bytes = (size_t)HW * BC * EX + (GNF_THREADS / 64) * 4 * 2 * sizeof(double);
     return bytes <= 100 * 1024 ? BC : 0;
 }
 
@@ -422,7 +429,7 @@ int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gam
     const int BC = gn_fused_bundle(x_dt, HW, C, groups);
     if (!BC) return 1;
     const int EX = x_dt == DT_F32 ? 4 : 2;
-    const size_t smem = (size_t)HW * BC * EX + GNF_THREADS * 4 * 2 * sizeof(double);
+    const size_t smem = (size_t)HW * BC * EX + (GNF_THREADS / 64) * 4 * 2 * sizeof(double);
     const dim3 grid(B * (C / BC));
 #define GNF(XF, YF)                                                                                                        \
     do {                                                                                                                   \
