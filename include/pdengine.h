@@ -179,7 +179,8 @@ void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches o
  *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "gn_fuse" (GroupNorm applied while the patch is staged, 0),
  *   "gn_single" (single-kernel LDS-slab GroupNorm where a sample's group bundle fits, 1),
  *   "big_tile" / "wide_tile" (256x160 / 256x320 GEMM tiles, 1), "dense_k" / "dense_tiles" (8-wave unsplit tile for
- *   linear layers with at most that many K steps, 40 / 128), "splitk_tiles" (split K below this many tiles, 384),
+ *   linear layers with at most that many K steps, 40 / 128), "short_k" (8-wave 128x160 tile at 16 waves per CU for
+ *   linear layers with at most that many K steps, 20), "splitk_tiles" (split K below this many tiles, 384),
  *   "splitk_fused" (in-kernel split-K finalize, 0), "gemm8" / "gemm8_tiles" (256x256 LDS-DMA GEMM, 0 / 256),
  *   "attn_legacy" (single-buffered attention kernel, 0), "diag" (timing diagnostic: GEMM operands all read row 0,
  *   results are WRONG, 0). */

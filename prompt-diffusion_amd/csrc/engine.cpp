@@ -584,6 +584,10 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
             const int rounds = (t3 + 255) / 256;
             if (opt_wide && splitk == 1 && m.taps == 1 && in.dt == T && t3 >= 256 && t3 * 100 >= rounds * 256 * 85) p.big_tile = 3;
         }
+        // short-K linear layers are HBM-bound (K <= 1280: 1.5-2.5x their traffic floor): what they need is loads and
+        // stores of one tile overlapping the MFMAs of others, i.e. many waves per CU rather than a big tile -- the
+        // 128 x 160 tile on 8 waves at <= 128 VGPRs runs 2 blocks = 16 waves per CU (+0.6 % end-to-end, interleaved A/B)
+        if (opt_short_k > 0 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_short_k) p.big_tile = 2;
         if (use8) p.big_tile = 4;
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
     }
