@@ -40,7 +40,7 @@ def all_gather_latents(latents, group=None, sizes=None):
         return t
     world = dist.get_world_size(group)
     if sizes is None:
-        n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+        n = torch.tensor([t.shape[0]], device=t.device if dist.get_backend(group) != "gloo" else "cpu", dtype=torch.int64)
         got = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(got, n, group=group)
         sizes = [int(s.item()) for s in got]
@@ -51,12 +51,14 @@ def all_gather_latents(latents, group=None, sizes=None):
         pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         t = torch.cat([t, pad])
     t = t.contiguous()
-    out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dev = t.device
     if dist.get_backend(group) == "gloo":
-        parts = list(out.chunk(world))
+        t = t.cpu()                       # CPU tests and single-GPU rehearsals: gloo gathers host tensors
+        parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t, group=group)
-        out = torch.cat(parts)
+        out = torch.cat(parts).to(dev)
     else:
+        out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
         dist.all_gather_into_tensor(out, t, group=group)
     if all(s == mx for s in sizes):
         return out
