@@ -104,8 +104,15 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     }
     const char* Ab = reinterpret_cast<const char*>(p.A);
     const char* Wb = reinterpret_cast<const char*>(p.W);
-    const int nchunks = p.Cin / BKE;
-    const int U = nchunks * 9;  // (chunk, tap) units; weights for unit u start at element (u%9)*Cin + (u/9)*BKE
+    // split-K (blockIdx.y): this slice owns the channel chunks [c0, c0 + nchunks); units are counted from the slice's start
+    const int chunks_all = p.Cin / BKE;
+    int c0 = 0, nchunks = chunks_all;
+    if (p.splitk > 1) {
+        const int per = (chunks_all + p.splitk - 1) / p.splitk;
+        c0 = blockIdx.y * per;
+        nchunks = min(chunks_all, c0 + per) - c0;
+    }
+    const int U = nchunks * 9;  // (chunk, tap) units of this slice; weights of a unit start at element tap*Cin + chunk*BKE
 
     // staging registers as named scalars (hipcc leaves small indexed arrays captured by these lambdas in scratch)
     static_assert(W_ITERS == 3, "weight staging below is written for 3 pieces");
@@ -187,33 +194,33 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     // ---- prologue: patch 0, weight tile of unit 0 in LDS; unit 1's weights in flight
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-    load_piece(I0{}, 0); load_piece(I1{}, 0); load_piece(I2{}, 0);
-    load_w(0, 0);
+    load_piece(I0{}, c0); load_piece(I1{}, c0); load_piece(I2{}, c0);
+    load_w(c0, 0);
     if constexpr (GN) {
         const float* src = p.gn_coef + (size_t)sample * p.Cin * 2;
         for (int i = tid; i < p.Cin * 2; i += NT) sCoef[i] = src[i];
         __syncthreads();
     }
-    store_one(I0{}, 0, 0); store_one(I1{}, 0, 0); store_one(I2{}, 0, 0);
-    load_piece(I3{}, 0); load_piece(I4{}, 0); load_piece(I5{}, 0);
+    store_one(I0{}, 0, c0); store_one(I1{}, 0, c0); store_one(I2{}, 0, c0);
+    load_piece(I3{}, c0); load_piece(I4{}, c0); load_piece(I5{}, c0);
     store_w(0);
-    store_one(I3{}, 0, 0); store_one(I4{}, 0, 0); store_one(I5{}, 0, 0);
+    store_one(I3{}, 0, c0); store_one(I4{}, 0, c0); store_one(I5{}, 0, c0);
     __syncthreads();
 
     // one (chunk, tap) unit.  Weight tile of unit u sits in LDS buffer u&1; the tile of unit u+1 is requested
     // at the top of the unit and written to the other buffer (last read in unit u-1) after the MFMAs.
-    auto unit = [&](auto TAPC, int c) __attribute__((always_inline)) {
+    auto unit = [&](auto TAPC, int lc) __attribute__((always_inline)) {
         constexpr int tap = decltype(TAPC)::value;
         constexpr int ky = tap / 3, kx = tap % 3;
-        const int u = c * 9 + tap;
+        const int c = c0 + lc;          // channel chunk (addresses); lc counts this slice's chunks (buffers, parity)
+        const int u = lc * 9 + tap;
         const int par = u & 1;
-        const bool nextc = c + 1 < nchunks;
+        const bool nextc = lc + 1 < nchunks;
         if (tap == 0 && nextc) { load_piece(I0{}, c + 1); load_piece(I1{}, c + 1); load_piece(I2{}, c + 1); }
         if (u + 1 < U) {
-            const int c2 = tap + 1 >= 9 ? c + 1 : c;
-            load_w(c2, u + 1 - c2 * 9);
+            load_w(tap + 1 >= 9 ? c + 1 : c, tap + 1 >= 9 ? 0 : tap + 1);
         }
-        const char* pa = sP + (c & 1) * G::P_BYTES;
+        const char* pa = sP + (lc & 1) * G::P_BYTES;
         const char* wa = sW + par * W_TILE;
         // keep the per-tap fragment addresses out of loop-invariant hoisting (they would otherwise live in
         // registers for the whole kernel and spill the accumulators)
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         if (u + 1 < U) store_w(par ^ 1);
         // next chunk's patch (two halves through the same registers) -> the other patch buffer, last read in chunk c-1
         if (nextc) {
-            const int nb = (c + 1) & 1;
+            const int nb = (lc + 1) & 1;
             if constexpr (tap == 2) { store_one(I0{}, nb, c + 1); load_piece(I3{}, c + 1); }
             if constexpr (tap == 3) { store_one(I1{}, nb, c + 1); load_piece(I4{}, c + 1); }
             if constexpr (tap == 4) { store_one(I2{}, nb, c + 1); load_piece(I5{}, c + 1); }
@@ -262,7 +269,8 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         unit(std::integral_constant<int, 8>{}, c);
     }
 
-    // ---- epilogue
+    // ---- epilogue (split-K: this slice's fp32 partial goes to its slab; splitk_finalize_kernel sums and finishes)
+    float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.slab) + (size_t)blockIdx.y * p.M * p.N : nullptr;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int oy = y0 + wm * 4 + m, ox = x0 + fr;
@@ -272,7 +280,8 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         for (int n = 0; n < 5; ++n) {
             const int gn = bn * BN + wn * 80 + n * 16 + fq * 4;
             if (gn >= p.N) continue;
-            epilogue4(p, gm, gn, sample, tok, acc[n][m]);
+            if (slab) *reinterpret_cast<f32x4*>(slab + (size_t)gm * p.N + gn) = acc[n][m];
+            else epilogue4(p, gm, gn, sample, tok, acc[n][m]);
         }
     }
 }
@@ -293,8 +302,9 @@ int launch_patch(const GemmParams& p, hipStream_t s) {
         attr_done = true;
     }
     const int mtiles = (p.M / (p.Hout * p.Wout)) * (p.Hout / TP) * (p.Wout / TP), ntiles = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kfn, dim3(mtiles * ntiles), dim3(NT), smem, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    hipLaunchKernelGGL(kfn, dim3(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1), dim3(NT), smem, s, p);
+    if (hipGetLastError() != hipSuccess) return 1;
+    return p.splitk > 1 ? launch_splitk_finalize(p, s) : 0;
 }
 
 }  // namespace
@@ -302,7 +312,7 @@ int launch_patch(const GemmParams& p, hipStream_t s) {
 // number of blocks the patch kernel would launch, or 0 when the shape does not qualify
 int conv_patch_tiles(const GemmParams& p, bool f32mode) {
     const int bke = f32mode ? 32 : 64;
-    if (p.taps != 9 || p.stride != 1 || p.splitk > 1) return 0;
+    if (p.taps != 9 || p.stride != 1) return 0;
     if (p.Hout % TP || p.Wout % TP || p.Cin % bke || p.K != 9 * p.Cin || p.act == 2 || p.vt_begin < p.N) return 0;
     if (p.a_dt != (f32mode ? DT_F32 : DT_BF16) || p.a_silu) return 0;
     if (p.Cin * 8 > 24 * 1024) return 0;

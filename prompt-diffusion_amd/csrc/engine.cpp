@@ -547,7 +547,18 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.gn_silu = gn_silu ? 1 : 0;
     p.diag = opt_diag;
     // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
-    const bool use_patch = opt_patch && conv_patch_tiles(p, f32) >= 192;
+    const int ptiles = opt_patch ? conv_patch_tiles(p, f32) : 0;
+    bool use_patch = ptiles >= 192;
+    // 16x16-level convs: too few 16x16 patches for the chip, but the patch kernel still beats the generic gather when the
+    // channel chunks are split across 2-4 slices (fp32 slabs + the same deterministic finalize pass as the GEMM's split-K)
+    int patch_split = 1;
+    if (!use_patch && opt_patch_split && ptiles >= opt_patch_split_tiles && !gn_coef && m.N % 4 == 0) {
+        const int chunks = p.Cin / (f32 ? 32 : 64);
+        int sk = (256 + ptiles - 1) / ptiles;
+        if (sk > chunks / 4) sk = chunks / 4;
+        if (sk > 4) sk = 4;
+        if (sk >= 2) { use_patch = true; patch_split = sk; }
+    }
     if (gn_coef && !use_patch) {
         pd_set_error("internal: fused GroupNorm requested for a conv that is not patch-eligible");
         return 1;
@@ -590,6 +601,13 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         if (opt_short_k > 0 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_short_k) p.big_tile = 2;
         if (use8) p.big_tile = 4;
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
+    }
+    if (use_patch && patch_split > 1) {
+        const size_t mk = arena.mark();
+        p.slab = arena.alloc((size_t)patch_split * p.M * m.N * sizeof(float));
+        p.splitk = patch_split;
+        if (!arena.dry && arena.top > arena.cap) { pd_set_error("no workspace for the conv split-K slabs"); return 1; }
+        arena.release(mk);   // stream-ordered: dead once the finalize pass has run
     }
     if (arena.dry) return 0;
     if (f32 && in.dt != DT_F32) {

@@ -236,6 +236,8 @@ struct pd_engine {
     bool opt_gn_single = true; // GroupNorm as one LDS-slab kernel where a sample's group bundle fits (32x32 and below)
     bool opt_graph = false;    // pd_ddim_sample: capture the step loop in a hipGraph and replay it on later calls with the same arguments
     int opt_short_k = 20;      // linear layers with at most this many K steps: 8-wave 128x160 tile at 16 waves per CU
+    bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
+    int opt_patch_split_tiles = 64;
     bool opt_gemm8 = false;    // 256 x 256 LDS-DMA tile kernel for big bf16 linear layers
     int opt_gemm8_tiles = 256;
     long long gemm8_launches = 0;

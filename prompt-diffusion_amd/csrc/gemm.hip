@@ -419,6 +419,15 @@ int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
 
 }  // namespace
 
+int launch_splitk_finalize(const GemmParams& p, hipStream_t s) {
+    if (p.splitk <= 1 || !p.slab || p.N % 4 || p.act == 2 || p.vt_begin < p.N) return 1;
+    long long total = (long long)p.M * (p.N / 4);
+    int nb = (int)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(nb), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 int gemm_tiles(int M, int N) { return ((M + 127) / 128) * ((N + 159) / 160); }
 
 int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid) {

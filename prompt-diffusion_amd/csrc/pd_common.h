@@ -121,6 +121,7 @@ struct AttnParams {
 
 int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid = nullptr);
 int gemm_tiles(int M, int N);
+int launch_splitk_finalize(const GemmParams& p, hipStream_t s);   // sums p.splitk fp32 slabs in slice order + epilogue
 int conv_patch_tiles(const GemmParams& p, bool f32mode);  // 0: shape not eligible for the LDS-patch conv kernel
 int launch_conv_patch(const GemmParams& p, bool f32mode, hipStream_t s);
 bool gemm8_eligible(const GemmParams& p);          // gemm8.hip: 256 x 256 LDS-DMA tile, bf16 linear layers

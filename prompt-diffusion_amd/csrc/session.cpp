@@ -669,6 +669,8 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "diag")) { e->opt_diag = (int)value; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }
+    if (!strcmp(key, "patch_split")) { e->opt_patch_split = value != 0; return 0; }
+    if (!strcmp(key, "patch_split_tiles")) { e->opt_patch_split_tiles = (int)value; return 0; }
     if (!strcmp(key, "gemm8")) { e->opt_gemm8 = value != 0; return 0; }
     if (!strcmp(key, "gemm8_tiles")) { e->opt_gemm8_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_tiles")) { e->opt_dense_tiles = (int)value; return 0; }

@@ -55,6 +55,31 @@ def test_conv2d(eng, B, Cin, H, W, Cout, k, stride, ups):
     assert relerr(got, ref) < TOL[eng.prec]
 
 
+def test_conv2d_patch_kernel_split_k(eng):
+    """LDS-patch conv with the channel chunks split over slices (the 16x16 level of the headline workload), forced onto a
+    small shape: fp32 slabs + finalize must match the oracle, epilogue (scale + residual) included, and be reproducible."""
+    g = rng(15)
+    B, Cin, H, Cout = 8, 512, 16, 168
+    x = g.standard_normal((B, Cin, H, H), dtype=np.float32)
+    w = (g.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = g.standard_normal(Cout, dtype=np.float32) * 0.1
+    r = g.standard_normal((B, Cout, H, H), dtype=np.float32)
+    ref = O.conv2d(x, w, b)
+    try:
+        eng.set_option("patch_split_tiles", 1)
+        got = eng.op_conv2d(x, w, b)
+        got_r = eng.op_conv2d(x, w, b, scale=0.5, residual=r, stream_out=True)
+        assert np.array_equal(eng.op_conv2d(x, w, b), got)
+        eng.set_option("patch_split", 0)
+        base = eng.op_conv2d(x, w, b)
+    finally:
+        eng.set_option("patch_split", 1)
+        eng.set_option("patch_split_tiles", 64)
+    assert relerr(got, ref) < TOL[eng.prec]
+    assert relerr(got_r, ref * 0.5 + r) < TOL[eng.prec]
+    assert relerr(base, ref) < TOL[eng.prec] and not np.array_equal(base, got)   # really a different kernel path
+
+
 def test_conv2d_epilogues(eng):
     g = rng(2)
     x = g.standard_normal((2, 64, 8, 8), dtype=np.float32)
