@@ -554,7 +554,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     int patch_split = 1;
     if (!use_patch && opt_patch_split && ptiles >= opt_patch_split_tiles && !gn_coef && m.N % 4 == 0) {
         const int chunks = p.Cin / (f32 ? 32 : 64);
-        int sk = (256 + ptiles - 1) / ptiles;
+        int sk = (opt_patch_split_fill + ptiles - 1) / ptiles;
         if (sk > chunks / 4) sk = chunks / 4;
         if (sk > 4) sk = 4;
         if (sk >= 2) { use_patch = true; patch_split = sk; }
@@ -577,7 +577,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         if (!use8 && !dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
             splitk = (512 + tiles - 1) / tiles;
             if (splitk > ktiles / 8) splitk = ktiles / 8;
-            if (splitk > 8) splitk = 8;
+            if (splitk > opt_splitk_max) splitk = opt_splitk_max;
             if (splitk < 1) splitk = 1;
         }
         if (splitk > 1) {

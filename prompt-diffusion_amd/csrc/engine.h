@@ -228,6 +228,7 @@ struct pd_engine {
     Session ses;
     int verbose = 0;
     bool opt_splitk_fused = false; // split-K sums + epilogue run in the last-arriving slice instead of a finalize kernel
+    int opt_splitk_max = 8;
     int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
     int opt_diag = 0;          // timing diagnostic (wrong results): GEMM operands all read row 0
@@ -238,6 +239,7 @@ struct pd_engine {
     int opt_short_k = 20;      // linear layers with at most this many K steps: 8-wave 128x160 tile at 16 waves per CU
     bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
     int opt_patch_split_tiles = 64;
+    int opt_patch_split_fill = 256;   // slices are chosen to reach about this many blocks
     bool opt_gemm8 = false;    // 256 x 256 LDS-DMA tile kernel for big bf16 linear layers
     int opt_gemm8_tiles = 256;
     long long gemm8_launches = 0;

@@ -662,6 +662,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "graph")) { e->opt_graph = value != 0; return 0; }
     if (!strcmp(key, "conv_patch")) { e->opt_patch = value != 0; return 0; }
     if (!strcmp(key, "splitk_fused")) { e->opt_splitk_fused = value != 0; return 0; }
+    if (!strcmp(key, "splitk_max")) { e->opt_splitk_max = (int)value; return 0; }
     if (!strcmp(key, "splitk_tiles")) { e->opt_splitk_tiles = (int)value; return 0; }
     if (!strcmp(key, "attn_legacy")) { e->opt_attn_legacy = value != 0; return 0; }
     if (!strcmp(key, "gn_fuse")) { e->opt_gn_fuse = value != 0; return 0; }
@@ -670,6 +671,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }
     if (!strcmp(key, "patch_split")) { e->opt_patch_split = value != 0; return 0; }
+    if (!strcmp(key, "patch_split_fill")) { e->opt_patch_split_fill = (int)value; return 0; }
     if (!strcmp(key, "patch_split_tiles")) { e->opt_patch_split_tiles = (int)value; return 0; }
     if (!strcmp(key, "gemm8")) { e->opt_gemm8 = value != 0; return 0; }
     if (!strcmp(key, "gemm8_tiles")) { e->opt_gemm8_tiles = (int)value; return 0; }
