@@ -42,6 +42,7 @@ def rng(seed):
     (12, 64, 32, 32, 320, 3, 1, False),  # LDS-patch kernel: 48 patches x 2 n-tiles... (>=192 blocks: 12*4*4)
     (13, 128, 16, 48, 168, 3, 1, False), # LDS-patch kernel, non-square, ragged N tile
     (50, 64, 16, 16, 96, 3, 1, True),    # LDS-patch kernel with fused nearest-x2 upsample (input 16x16 -> 32x32)
+    (16, 1280, 16, 16, 1280, 3, 1, False),  # the headline workload's 16x16-level conv: LDS-patch kernel, channel chunks split over 2 slices
 ])
 def test_conv2d(eng, B, Cin, H, W, Cout, k, stride, ups):
     g = rng(1)
