@@ -165,6 +165,22 @@ def test_geglu(eng, M, C):
     assert relerr(eng.op_linear(x, w, b, geglu=True), a * O.gelu(gate)) < TOL[eng.prec]
 
 
+def test_headline_gemm_tiles_against_oracle(eng):
+    """The big-tile instantiations only chosen at the headline workload's sizes: GEGLU on the 256 x 320 tile (M x N large
+    enough for >= 256 such tiles) and a K = 2560 projection on the 256 x 160 tile."""
+    g = rng(16)
+    M, K, N = 14336, 320, 2560
+    x = g.standard_normal((M, K), dtype=np.float32)
+    w = (g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = g.standard_normal(N, dtype=np.float32) * 0.1
+    a, gate = np.split(O.linear(x, w, b), 2, axis=-1)
+    assert relerr(eng.op_linear(x, w, b, geglu=True), a * O.gelu(gate)) < TOL[eng.prec]
+    M, K, N = 16384, 2560, 640
+    x = g.standard_normal((M, K), dtype=np.float32)
+    w = (g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    assert relerr(eng.op_linear(x, w, None), O.linear(x, w)) < TOL[eng.prec]
+
+
 @pytest.mark.parametrize("B,C,H,W,eps,silu", [(2, 64, 8, 8, 1e-5, True), (3, 320, 16, 16, 1e-6, False),
                                                (1, 960, 4, 4, 1e-5, True), (2, 128, 5, 3, 1e-5, True),
                                                (1, 2560, 8, 8, 1e-5, True)])
