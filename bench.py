@@ -168,11 +168,24 @@ def main():
                             ("attn_kernel", 2)):
                 ms, n, fl = eng.profile_read(k)
                 classes[name] = dict(ms=ms, launches=n, avg_us=1e3 * ms / max(n, 1), tflops=fl / max(ms, 1e-9) / 1e9)
+            # HBM view of the short-K linear layers (K <= 1280: the igemm launches that are bandwidth- rather than
+            # MFMA-bound): algorithmic bytes = the A rows + the weights + the output, bf16, each moved once
+            import csv, tempfile
+            with tempfile.NamedTemporaryFile("r", suffix=".csv") as tf:
+                eng.profile_dump(tf.name)
+                rows = [r for r in csv.DictReader(open(tf.name)) if r["klass"] == "1" and int(r["K"]) <= 1280]
+            if rows:
+                by = sum((int(r["M"]) * int(r["K"]) + int(r["N"]) * int(r["K"]) + int(r["M"]) * int(r["N"])) * 2 for r in rows)
+                ms_s = sum(float(r["ms"]) for r in rows)
+                classes["igemm_kernel[linear, K<=1280: HBM view]"] = dict(
+                    ms=ms_s, launches=len(rows), avg_us=1e3 * ms_s / len(rows), algorithmic_gb_per_s=by / ms_s / 1e6,
+                    frac_of_8_tb_s=by / ms_s / 1e6 / 8000.0)
             eng.set_option("profile", 0)
             eng.set_option("two_streams", 0 if args.single_stream else 1)
             # dominant kernel by device time: igemm_kernel (every instantiation: linear / conv1x1 / generic conv3x3).
             # Each bracket is ONE launch of that kernel (split-K finalize excluded), so avg_launch_us is comparable
             # with rocprofv3's call-weighted average over the igemm_kernel<...> rows (profiles/).
+            # (the HBM-view entry above is a sub-population of igemm_kernel[linear/conv1x1], not added again)
             ms_g = classes["igemm_kernel[conv3x3]"]["ms"] + classes["igemm_kernel[linear/conv1x1]"]["ms"]
             n_g = classes["igemm_kernel[conv3x3]"]["launches"] + classes["igemm_kernel[linear/conv1x1]"]["launches"]
             fl_g = sum(classes[k]["tflops"] * classes[k]["ms"] for k in ("igemm_kernel[conv3x3]", "igemm_kernel[linear/conv1x1]"))
