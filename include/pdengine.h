@@ -29,6 +29,10 @@ extern "C" {
 /* arithmetic mode of the engine */
 #define PD_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate / norm statistics / softmax */
 #define PD_PREC_F32 1  /* fp32 MFMA (v_mfma_f32_16x16x4_f32): bit-faithful fp32 arithmetic */
+#define PD_PREC_F16 2  /* fp16 MFMA operands (the reference's own GPU dtype, README.md:44-45 torch_dtype=torch.float16;
+                          same MFMA rate as bf16, 3 more mantissa bits), fp32 accumulate / norm statistics / softmax */
+#define PD_PREC_F16X2 3 /* fp32 storage; every MFMA operand split into fp16 hi + lo in registers, two fp16 MFMAs per
+                           product (all four cross terms): ~22-bit operands, fp32-class results at 4x the fp32 MFMA rate */
 
 /* where caller-owned I/O buffers live */
 #define PD_MEM_HOST 0
@@ -64,7 +68,7 @@ typedef struct pd_config {
     double linear_start;      /* 0.00085 (double: the schedule is derived in float64, util.py:22-25) */
     double linear_end;        /* 0.0120 */
     int32_t precision;        /* PD_PREC_* */
-    int32_t stream_f32;       /* PD_PREC_BF16 only: keep the residual stream (block outputs) in fp32 */
+    int32_t stream_f32;       /* PD_PREC_BF16 / PD_PREC_F16: keep the residual stream (block outputs) in fp32 */
     /* first-stage KL-VAE decoder (models/cldm_v15.yaml:64-85).  vae_ch = 0: not built */
     int32_t vae_ch;           /* 128 */
     int32_t vae_num_levels;   /* 4 */
@@ -182,11 +186,10 @@ void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches o
  *   "big_tile" / "wide_tile" (256x160 / 256x320 GEMM tiles, 1), "dense_k" / "dense_tiles" (8-wave unsplit tile for
  *   linear layers with at most that many K steps, 40 / 128), "short_k" (8-wave 128x160 tile at 16 waves per CU for
  *   linear layers with at most that many K steps, 20), "splitk_tiles" (split K below this many tiles, 384),
- *   "splitk_fused" (in-kernel split-K finalize, 0), "gemm8" / "gemm8_tiles" (256x256 LDS-DMA GEMM, 0 / 256),
- *   "attn_legacy" (single-buffered attention kernel, 0), "diag" (timing diagnostic: GEMM operands all read row 0,
- *   results are WRONG, 0). */
+ *   "splitk_fused" (in-kernel split-K finalize, 0),
+ *   "attn_legacy" (single-buffered attention kernel, 0). */
 int pd_set_option(pd_engine* e, const char* key, int64_t value);
-int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches", "steps", "gemm8_launches" */
+int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches", "steps" */
 /* Per-launch timing: while option "profile" is 1 the engine brackets every contraction launch with HIP
  * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel on a conv1x1/linear,
  * 2 = attention, 3 = conv3x3_patch_kernel, -1 = all.  One bracket = one launch (split-K finalize excluded).

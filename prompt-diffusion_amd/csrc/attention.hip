@@ -21,21 +21,12 @@ namespace {
 
 constexpr int TK = 64;  // keys per tile
 
-template <bool F32>
-__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc) {
-    if constexpr (F32) {
-        const float* af = reinterpret_cast<const float*>(&a);
-        const float* bf = reinterpret_cast<const float*>(&b);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
-    } else {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                      acc, 0, 0, 0);
-    }
-}
+template <int P>
+__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc) { mma_raw<P>(a, b, acc); }
 
-template <bool F32, int DH>
+template <int P, int DH>
 struct AttnCfg {
+    static constexpr bool F32 = prec_f32_storage(P);
     static constexpr int EB = F32 ? 4 : 2;
     static constexpr int VEC = 16 / EB;
     static constexpr int NCH = DH * EB / 16;      // 16-byte chunks per head row
@@ -48,9 +39,10 @@ struct AttnCfg {
     static_assert((DH * EB) % 16 == 0, "head dim must fill whole 16-byte chunks");
 };
 
-template <bool F32, int DH>
+template <int P, int DH>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
-    using Cfg = AttnCfg<F32, DH>;
+    using Cfg = AttnCfg<P, DH>;
+    constexpr bool F32 = prec_f32_storage(P);
     constexpr int EB = Cfg::EB, VEC = Cfg::VEC, NCH = Cfg::NCH, KS = Cfg::KS, NTD = Cfg::NTD;
     constexpr int KROW = Cfg::KROW, VROW = Cfg::VROW, VCH = Cfg::VCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,8 +124,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             for (int kt = 0; kt < 4; ++kt) kf[kt] = *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * KROW + (ks * 4 + fq) * 16);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                mma16<F32>(kf[kt], qf[ks][0], s[kt][0]);
-                mma16<F32>(kf[kt], qf[ks][1], s[kt][1]);
+                mma16<P>(kf[kt], qf[ks][0], s[kt][0]);
+                mma16<P>(kf[kt], qf[ks][1], s[kt][1]);
             }
         }
         // ---- online softmax (base-2), query = lane&15 of each query tile
@@ -178,8 +170,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int n = 0; n < NTD; ++n) {
                     const uint4 vf = *reinterpret_cast<const uint4*>(sV + (n * 16 + fr) * VROW + (kt * 16 + fq * 4) * 4);
-                    mma16<true>(vf, pf[0], o[n][0]);
-                    mma16<true>(vf, pf[1], o[n][1]);
+                    mma16<P>(vf, pf[0], o[n][0]);
+                    mma16<P>(vf, pf[1], o[n][1]);
                 }
             }
         } else {
@@ -188,10 +180,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 uint4 pf[2];
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
-                    pf[qt].x = pack2bf(s[2 * u][qt][0], s[2 * u][qt][1]);
-                    pf[qt].y = pack2bf(s[2 * u][qt][2], s[2 * u][qt][3]);
-                    pf[qt].z = pack2bf(s[2 * u + 1][qt][0], s[2 * u + 1][qt][1]);
-                    pf[qt].w = pack2bf(s[2 * u + 1][qt][2], s[2 * u + 1][qt][3]);
+                    pf[qt].x = pack2<P>(s[2 * u][qt][0], s[2 * u][qt][1]);
+                    pf[qt].y = pack2<P>(s[2 * u][qt][2], s[2 * u][qt][3]);
+                    pf[qt].z = pack2<P>(s[2 * u + 1][qt][0], s[2 * u + 1][qt][1]);
+                    pf[qt].w = pack2<P>(s[2 * u + 1][qt][2], s[2 * u + 1][qt][3]);
                 }
 #pragma unroll
                 for (int n = 0; n < NTD; ++n) {
@@ -199,8 +191,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                     const uint2 lo = *reinterpret_cast<const uint2*>(row + ((2 * u) * 16 + fq * 4) * 2);
                     const uint2 hi = *reinterpret_cast<const uint2*>(row + ((2 * u + 1) * 16 + fq * 4) * 2);
                     const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    mma16<false>(vf, pf[0], o[n][0]);
-                    mma16<false>(vf, pf[1], o[n][1]);
+                    mma16<P>(vf, pf[0], o[n][0]);
+                    mma16<P>(vf, pf[1], o[n][1]);
                 }
             }
         }
@@ -220,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             const int d = n * 16 + fq * 4;
             if (d >= DH) continue;
             f32x4 v = o[n][qt] * inv;
-            store4(p.O, (size_t)b * p.o_bs + (size_t)q * p.ldo + (size_t)h * DH + d, F32 ? DT_F32 : DT_BF16, v);
+            store4(p.O, (size_t)b * p.o_bs + (size_t)q * p.ldo + (size_t)h * DH + d, F32 ? (int)DT_F32 : P, v);
         }
     }
 }
@@ -264,8 +256,19 @@ __device__ __forceinline__ float bf16_ceil(float x) {
     u = x >= 0.f ? (u + 0xFFFFu) & 0xFFFF0000u : u & 0xFFFF0000u;
     return __uint_as_float(u);
 }
+// an fp16-representable value >= x within two ulps of it (|x| far below 65504: logits in exp2 units)
+__device__ __forceinline__ float f16_ceil(float x) {
+    float r = h2f(f2h(x));
+    if (r < x) r = h2f(f2h(x + fabsf(x) * 0x1p-10f + 1e-7f));
+    return r;
+}
+template <int P> __device__ __forceinline__ float ref_ceil(float x) {
+    if constexpr (P == DT_F16) return f16_ceil(x); else return bf16_ceil(x);
+}
+template <int P> struct One16 { static constexpr unsigned v = P == DT_F16 ? 0x3C00u : 0x3F80u; };   // 1.0 in the 2-byte type
 
-template <int DH>
+// P: DT_BF16 or DT_F16
+template <int DH, int P>
 __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnParams p) {
     using Cfg = Attn2Cfg<DH>;
     auto kpos = [](int row, int c) __attribute__((always_inline)) { return Cfg::KSWZ ? (c ^ ((row >> 1) & 7)) : c; };   // chunk slot of K row
@@ -303,8 +306,11 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
             for (int ks = 0; ks < KS; ++ks) {
                 unsigned* w = reinterpret_cast<unsigned*>(&qf[ks][qt]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    w[j] = pack2bf(__uint_as_float(w[j] << 16) * sl2, __uint_as_float(w[j] & 0xFFFF0000u) * sl2);
+                for (int j = 0; j < 4; ++j) {
+                    float lo, hi;
+                    unpack2<P>(w[j], lo, hi);
+                    w[j] = pack2<P>(lo * sl2, hi * sl2);
+                }
             }
     }
     // zero the pad chunks / pad rows of both LDS buffers once (they never change)
@@ -393,11 +399,11 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
     __syncthreads();   // zero fill done before the first tile lands on top of it
     if constexpr (SUBM) {   // K'[key][DH] = 1.0 in both buffers
         for (int i = tid; i < 2 * TK; i += 256)
-            *reinterpret_cast<unsigned*>(smem + (i / TK) * (Cfg::K_BYTES + Cfg::V_BYTES) + (i % TK) * KROW + kpos(i % TK, NCH) * 16) = 0x3F80u;
+            *reinterpret_cast<unsigned*>(smem + (i / TK) * (Cfg::K_BYTES + Cfg::V_BYTES) + (i % TK) * KROW + kpos(i % TK, NCH) * 16) = One16<P>::v;
     }
     if constexpr (ONES) {   // V^T row DH = 1.0 for all 64 keys, both buffers
         for (int i = tid; i < 2 * (TK / 2); i += 256)
-            *reinterpret_cast<unsigned*>(smem + (i / (TK / 2)) * (Cfg::K_BYTES + Cfg::V_BYTES) + Cfg::K_BYTES + DH * VROW + (i % (TK / 2)) * 4) = 0x3F803F80u;
+            *reinterpret_cast<unsigned*>(smem + (i / (TK / 2)) * (Cfg::K_BYTES + Cfg::V_BYTES) + Cfg::K_BYTES + DH * VROW + (i % (TK / 2)) * 4) = One16<P>::v * 0x10001u;
     }
     store_tile(0);
     __syncthreads();
@@ -418,8 +424,8 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const uint4 kf = *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * KROW + kpos(fr, ks * 4 + fq) * 16);
-                mma16<false>(kf, qf[ks][0], s[kt][0]);
-                mma16<false>(kf, qf[ks][1], s[kt][1]);
+                mma16<P>(kf, qf[ks][0], s[kt][0]);
+                mma16<P>(kf, qf[ks][1], s[kt][1]);
             }
         }
         if (t0 + TK > p.Nk || p.causal) {  // ragged last tile: mask the pad keys; causal: the keys after the query
@@ -453,10 +459,10 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
                     float m = mx[qt];
                     m = fmaxf(m, __shfl_xor(m, 16));
                     m = fmaxf(m, __shfl_xor(m, 32));
-                    const float mnew = (t == 0 || m > 0.f) ? bf16_ceil(mref[qt] + m) : mref[qt];
+                    const float mnew = (t == 0 || m > 0.f) ? ref_ceil<P>(mref[qt] + m) : mref[qt];
                     const float delta = mnew - mref[qt];
                     mref[qt] = mnew;
-                    if (fq == FQM) qf[KSM][qt].x = __float_as_uint(-mnew) >> 16;   // Q'[q][DH] = -m_ref (Q'[q][DH+1] = 0)
+                    if (fq == FQM) qf[KSM][qt].x = cvt16<P>(-mnew);   // Q'[q][DH] = -m_ref (Q'[q][DH+1] = 0)
 #pragma unroll
                     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -518,10 +524,10 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
             uint4 pf[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                pf[qt].x = pack2bf(s[2 * u][qt][0], s[2 * u][qt][1]);
-                pf[qt].y = pack2bf(s[2 * u][qt][2], s[2 * u][qt][3]);
-                pf[qt].z = pack2bf(s[2 * u + 1][qt][0], s[2 * u + 1][qt][1]);
-                pf[qt].w = pack2bf(s[2 * u + 1][qt][2], s[2 * u + 1][qt][3]);
+                pf[qt].x = pack2<P>(s[2 * u][qt][0], s[2 * u][qt][1]);
+                pf[qt].y = pack2<P>(s[2 * u][qt][2], s[2 * u][qt][3]);
+                pf[qt].z = pack2<P>(s[2 * u + 1][qt][0], s[2 * u + 1][qt][1]);
+                pf[qt].w = pack2<P>(s[2 * u + 1][qt][2], s[2 * u + 1][qt][3]);
             }
 #pragma unroll
             for (int n = 0; n < NTD; ++n) {
@@ -529,8 +535,8 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
                 const uint2 lo = *reinterpret_cast<const uint2*>(row + ((2 * u) * 16 + fq * 4) * 2);
                 const uint2 hi = *reinterpret_cast<const uint2*>(row + ((2 * u + 1) * 16 + fq * 4) * 2);
                 const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                mma16<false>(vf, pf[0], o[n][0]);
-                mma16<false>(vf, pf[1], o[n][1]);
+                mma16<P>(vf, pf[0], o[n][0]);
+                mma16<P>(vf, pf[1], o[n][1]);
             }
         }
         if (t + 1 < ntiles) store_tile(buf ^ 1);   // buffer buf^1 was last read in tile t-1 (barrier below)
@@ -554,71 +560,69 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
         for (int n = 0; n < NTD; ++n) {
             const int d = n * 16 + fq * 4;
             if (d >= DH) continue;
-            store4(p.O, (size_t)b * p.o_bs + (size_t)q * p.ldo + (size_t)h * DH + d, DT_BF16, o[n][qt] * inv);
+            store4(p.O, (size_t)b * p.o_bs + (size_t)q * p.ldo + (size_t)h * DH + d, P, o[n][qt] * inv);
         }
     }
 }
 
-template <int DH>
+template <int DH, int P>
 int launch_attn2(const AttnParams& p, hipStream_t s) {
     using Cfg = Attn2Cfg<DH>;
-    static bool attr_done = false;
-    auto kfn = attn2_kernel<DH>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Cfg::SMEM) != hipSuccess)
-            return 1;
-        attr_done = true;
-    }
+    auto kfn = attn2_kernel<DH, P>;
+    static unsigned long long attr_done = 0;
+    if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), Cfg::SMEM, &attr_done)) return 1;
     dim3 grid((p.Nq + 127) / 128, p.B * p.heads);
     hipLaunchKernelGGL(kfn, grid, dim3(256), Cfg::SMEM, s, p);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-template <bool F32, int DH>
+template <int P, int DH>
 int launch_dh(const AttnParams& p, hipStream_t s) {
-    using Cfg = AttnCfg<F32, DH>;
-    static bool attr_done = false;
-    auto kfn = attn_kernel<F32, DH>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Cfg::SMEM) != hipSuccess)
-            return 1;
-        attr_done = true;
-    }
+    using Cfg = AttnCfg<P, DH>;
+    auto kfn = attn_kernel<P, DH>;
+    static unsigned long long attr_done = 0;
+    if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), Cfg::SMEM, &attr_done)) return 1;
     dim3 grid((p.Nq + 127) / 128, p.B * p.heads);
     hipLaunchKernelGGL(kfn, grid, dim3(256), Cfg::SMEM, s, p);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-template <bool F32>
+template <int P>
 int launch_prec(const AttnParams& p, hipStream_t s) {
+    if constexpr (!prec_f32_storage(P)) {
+        if (!p.legacy) {
+            switch (p.dh) {
+                case 8: return launch_attn2<8, P>(p, s);
+                case 16: return launch_attn2<16, P>(p, s);
+                case 32: return launch_attn2<32, P>(p, s);
+                case 40: return launch_attn2<40, P>(p, s);
+                case 64: return launch_attn2<64, P>(p, s);
+                case 80: return launch_attn2<80, P>(p, s);
+                default: break;
+            }
+        }
+    }
     switch (p.dh) {
-        case 8: return launch_dh<F32, 8>(p, s);
-        case 16: return launch_dh<F32, 16>(p, s);
-        case 32: return launch_dh<F32, 32>(p, s);
-        case 40: return launch_dh<F32, 40>(p, s);
-        case 64: return launch_dh<F32, 64>(p, s);
-        case 80: return launch_dh<F32, 80>(p, s);
-        case 160: return launch_dh<F32, 160>(p, s);
+        case 8: return launch_dh<P, 8>(p, s);
+        case 16: return launch_dh<P, 16>(p, s);
+        case 32: return launch_dh<P, 32>(p, s);
+        case 40: return launch_dh<P, 40>(p, s);
+        case 64: return launch_dh<P, 64>(p, s);
+        case 80: return launch_dh<P, 80>(p, s);
+        case 160: return launch_dh<P, 160>(p, s);
         default: return 2;
     }
 }
 
 }  // namespace
 
-int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s) {
+int launch_attention(const AttnParams& p, int prec, hipStream_t s) {
     if (p.Nq <= 0 || p.Nk <= 0) return 0;
-    if (!f32mode && !p.legacy) {
-        switch (p.dh) {
-            case 8: return launch_attn2<8>(p, s);
-            case 16: return launch_attn2<16>(p, s);
-            case 32: return launch_attn2<32>(p, s);
-            case 40: return launch_attn2<40>(p, s);
-            case 64: return launch_attn2<64>(p, s);
-            case 80: return launch_attn2<80>(p, s);
-            default: break;
-        }
+    switch (prec) {
+        case DT_F32: return launch_prec<DT_F32>(p, s);
+        case PREC_F16X2: return launch_prec<PREC_F16X2>(p, s);
+        case DT_BF16: return launch_prec<DT_BF16>(p, s);
+        case DT_F16: return launch_prec<DT_F16>(p, s);
+        default: return 1;
     }
-    return f32mode ? launch_prec<true>(p, s) : launch_prec<false>(p, s);
 }

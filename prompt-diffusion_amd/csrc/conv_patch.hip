@@ -42,9 +42,10 @@ struct PatchGeom {
     static constexpr int SMEM = 2 * P_BYTES + 2 * W_TILE;
 };
 
-template <bool F32, int UPS, bool GN>
+template <int P, int UPS, bool GN>
 __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     using G = PatchGeom<UPS>;
+    constexpr bool F32 = prec_f32_storage(P);
     constexpr int EB = F32 ? 4 : 2;
     constexpr int VEC = 16 / EB;
     constexpr int BKE = ROWB / EB;
@@ -143,12 +144,7 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) f[e] = t[e];
             } else {
-                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f[2 * e] = __uint_as_float(w[e] << 16);
-                    f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
-                }
+                unpack8<P>(r, f);
             }
 #pragma unroll
             for (int e = 0; e < VEC; e += 2) {
@@ -162,7 +158,7 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = f[e];
             } else {
-                v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+                v = pack8<P>(f);
             }
         }
         if (!ok) v = make_uint4(0, 0, 0, 0);
@@ -228,20 +224,20 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         asm volatile("" : "+v"(frv));
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 af[4];
+            typename Frag<P>::A af[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int py = wm * 4 + m;
                 const int prow = (((y0 - 1 + py + ky) >> UPS) - sy0) * PW + (((x0 - 1 + frv + kx) >> UPS) - sx0);
-                af[m] = *reinterpret_cast<const uint4*>(pa + swzp(prow, ks * 4 + fq));
+                af[m] = prep_a<P>(*reinterpret_cast<const uint4*>(pa + swzp(prow, ks * 4 + fq)));
             }
             // (row>>1)&7 of a weight row wn*80 + n*16 + fr does not depend on n or wn: one base + n*2048
             const char* wrow = wa + swzp(wn * 80 + frv, ks * 4 + fq);
 #pragma unroll
             for (int n = 0; n < 5; ++n) {
-                const uint4 wf = *reinterpret_cast<const uint4*>(wrow + n * 16 * ROWB);
+                const typename Frag<P>::W wf = prep_w<P>(*reinterpret_cast<const uint4*>(wrow + n * 16 * ROWB));
 #pragma unroll
-                for (int m = 0; m < 4; ++m) mma<F32>(wf, af[m], acc[n][m]);
+                for (int m = 0; m < 4; ++m) mma<P>(wf, af[m], acc[n][m]);
             }
         }
         if (u + 1 < U) store_w(par ^ 1);
@@ -288,19 +284,14 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
 
 constexpr int COEF_BYTES_MAX = 24 * 1024;   // [Cin <= 3072][2] floats behind the staging buffers
 
-template <bool F32, int UPS, bool GN>
+template <int P, int UPS, bool GN>
 int launch_patch(const GemmParams& p, hipStream_t s) {
     using G = PatchGeom<UPS>;
-    static bool attr_done = false;
-    auto kfn = conv3x3_patch_kernel<F32, UPS, GN>;
+    static unsigned long long attr_done = 0;
+    auto kfn = conv3x3_patch_kernel<P, UPS, GN>;
     const int smem = G::SMEM + (GN ? COEF_BYTES_MAX : 0);
     if (GN && p.Cin * 8 > COEF_BYTES_MAX) return 1;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-            hipSuccess)
-            return 1;
-        attr_done = true;
-    }
+    if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), smem, &attr_done)) return 1;
     const int mtiles = (p.M / (p.Hout * p.Wout)) * (p.Hout / TP) * (p.Wout / TP), ntiles = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL(kfn, dim3(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1), dim3(NT), smem, s, p);
     if (hipGetLastError() != hipSuccess) return 1;
@@ -310,21 +301,33 @@ int launch_patch(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 // number of blocks the patch kernel would launch, or 0 when the shape does not qualify
-int conv_patch_tiles(const GemmParams& p, bool f32mode) {
-    const int bke = f32mode ? 32 : 64;
+int conv_patch_tiles(const GemmParams& p, int prec) {
+    const int bke = prec_f32_storage(prec) ? 32 : 64;
     if (p.taps != 9 || p.stride != 1) return 0;
     if (p.Hout % TP || p.Wout % TP || p.Cin % bke || p.K != 9 * p.Cin || p.act == 2 || p.vt_begin < p.N) return 0;
-    if (p.a_dt != (f32mode ? DT_F32 : DT_BF16) || p.a_silu) return 0;
+    if (p.a_dt != (prec_f32_storage(prec) ? (int)DT_F32 : prec) || p.a_silu) return 0;
     if (p.Cin * 8 > 24 * 1024) return 0;
     if ((p.Hin << p.ups) != p.Hout || (p.Win << p.ups) != p.Wout) return 0;
     return (p.M / (p.Hout * p.Wout)) * (p.Hout / TP) * (p.Wout / TP) * ((p.N + BN - 1) / BN);
 }
 
-int launch_conv_patch(const GemmParams& p, bool f32mode, hipStream_t s) {
+namespace {
+template <int P>
+int launch_patch_prec(const GemmParams& p, hipStream_t s) {
     if (p.gn_coef) {
         if (p.ups) return 1;   // GroupNorm never feeds an upsampling conv in this network
-        return f32mode ? launch_patch<true, 0, true>(p, s) : launch_patch<false, 0, true>(p, s);
+        return launch_patch<P, 0, true>(p, s);
     }
-    if (p.ups) return f32mode ? launch_patch<true, 1, false>(p, s) : launch_patch<false, 1, false>(p, s);
-    return f32mode ? launch_patch<true, 0, false>(p, s) : launch_patch<false, 0, false>(p, s);
+    return p.ups ? launch_patch<P, 1, false>(p, s) : launch_patch<P, 0, false>(p, s);
+}
+}  // namespace
+
+int launch_conv_patch(const GemmParams& p, int prec, hipStream_t s) {
+    switch (prec) {
+        case DT_F32: return launch_patch_prec<DT_F32>(p, s);
+        case PREC_F16X2: return launch_patch_prec<PREC_F16X2>(p, s);
+        case DT_BF16: return launch_patch_prec<DT_BF16>(p, s);
+        case DT_F16: return launch_patch_prec<DT_F16>(p, s);
+        default: return 1;
+    }
 }

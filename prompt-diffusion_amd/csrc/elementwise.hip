@@ -23,7 +23,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, void* __restri
         const int b = (int)(bp / HW);
         const float v = c < C ? scale * in[((long long)b * C + c) * HW + p] : 0.f;
         if (out_dt == DT_F32) reinterpret_cast<float*>(out)[i] = v;
-        else reinterpret_cast<uint16_t*>(out)[i] = f2bf(v);
+        else reinterpret_cast<uint16_t*>(out)[i] = cvt16_rt(v, out_dt);
     }
 }
 
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int i = lane; i < n; i += 64) {
         const float v = __expf(x[i] - m) * inv;
         if (out_dt == DT_F32) reinterpret_cast<float*>(out)[(size_t)row * n + i] = v;
-        else reinterpret_cast<uint16_t*>(out)[(size_t)row * n + i] = f2bf(v);
+        else reinterpret_cast<uint16_t*>(out)[(size_t)row * n + i] = cvt16_rt(v, out_dt);
     }
 }
 
@@ -64,9 +64,9 @@ __global__ void embed_tokens_kernel(const int* __restrict__ ids, const void* __r
         if (dt == DT_F32)
             v = reinterpret_cast<const float*>(tok)[(size_t)id * tok_ld + c] + reinterpret_cast<const float*>(pos)[(size_t)l * pos_ld + c];
         else
-            v = bf2f(reinterpret_cast<const uint16_t*>(tok)[(size_t)id * tok_ld + c]) + bf2f(reinterpret_cast<const uint16_t*>(pos)[(size_t)l * pos_ld + c]);
+            v = cvt32_rt(reinterpret_cast<const uint16_t*>(tok)[(size_t)id * tok_ld + c], dt) + cvt32_rt(reinterpret_cast<const uint16_t*>(pos)[(size_t)l * pos_ld + c], dt);
         if (out_dt == DT_F32) reinterpret_cast<float*>(out)[i] = v;
-        else reinterpret_cast<uint16_t*>(out)[i] = f2bf(v);
+        else reinterpret_cast<uint16_t*>(out)[i] = cvt16_rt(v, out_dt);
     }
 }
 
@@ -79,7 +79,7 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ in, int in_dt, floa
         const int c = (int)(bc % C);
         const int b = (int)(bc / C);
         const long long j = ((long long)b * HW + p) * Cpad + c;
-        const float v = in_dt == DT_F32 ? reinterpret_cast<const float*>(in)[j] : bf2f(reinterpret_cast<const uint16_t*>(in)[j]);
+        const float v = in_dt == DT_F32 ? reinterpret_cast<const float*>(in)[j] : cvt32_rt(reinterpret_cast<const uint16_t*>(in)[j], in_dt);
         out[i] = v * scale;
     }
 }
@@ -92,7 +92,7 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, void* __restrict_
         const long long r = i / Cpad;
         const float v = c < C ? in[r * C + c] : 0.f;
         if (out_dt == DT_F32) reinterpret_cast<float*>(out)[i] = v;
-        else reinterpret_cast<uint16_t*>(out)[i] = f2bf(v);
+        else reinterpret_cast<uint16_t*>(out)[i] = cvt16_rt(v, out_dt);
     }
 }
 
@@ -143,7 +143,7 @@ __global__ void cfg_ddim_kernel(const void* __restrict__ eps, int eps_dt, int ep
         const int p = (int)(bp % HW);
         const int b = (int)(bp / HW);
         auto ld = [&](long long j) {
-            return eps_dt == DT_F32 ? reinterpret_cast<const float*>(eps)[j] : bf2f(reinterpret_cast<const uint16_t*>(eps)[j]);
+            return eps_dt == DT_F32 ? reinterpret_cast<const float*>(eps)[j] : cvt32_rt(reinterpret_cast<const uint16_t*>(eps)[j], eps_dt);
         };
         float e;
         if (use_cfg) {
@@ -172,8 +172,8 @@ __global__ void cfg_ddim_kernel(const void* __restrict__ eps, int eps_dt, int ep
             if (use_cfg) xo[(long long)B * HW * Cpad + xi] = xp;
         } else {
             uint16_t* xo = reinterpret_cast<uint16_t*>(x_in);
-            xo[xi] = f2bf(xp);
-            if (use_cfg) xo[(long long)B * HW * Cpad + xi] = f2bf(xp);
+            xo[xi] = cvt16_rt(xp, x_in_dt);
+            if (use_cfg) xo[(long long)B * HW * Cpad + xi] = cvt16_rt(xp, x_in_dt);
         }
     }
 }
@@ -201,7 +201,7 @@ __global__ void fill_random_kernel(void* __restrict__ p, int dt, long long n, fl
         const float z = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
         const float v = shift + scale * z;
         if (dt == DT_F32) reinterpret_cast<float*>(p)[i] = v;
-        else reinterpret_cast<uint16_t*>(p)[i] = f2bf(v);
+        else reinterpret_cast<uint16_t*>(p)[i] = cvt16_rt(v, dt);
     }
 }
 

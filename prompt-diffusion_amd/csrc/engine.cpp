@@ -225,9 +225,14 @@ void pd_engine::build_middle(const std::string& prefix, NetW& net) {
 }
 
 int pd_engine::build() {
-    f32 = cfg.precision == PD_PREC_F32;
-    T = f32 ? DT_F32 : DT_BF16;
-    S = (f32 || cfg.stream_f32) ? DT_F32 : DT_BF16;
+    if (cfg.precision < PD_PREC_BF16 || cfg.precision > PD_PREC_F16X2) {
+        pd_set_error("unknown precision %d (PD_PREC_BF16 / PD_PREC_F32 / PD_PREC_F16 / PD_PREC_F16X2)", cfg.precision);
+        return 1;
+    }
+    f32 = cfg.precision == PD_PREC_F32 || cfg.precision == PD_PREC_F16X2;
+    T = f32 ? DT_F32 : cfg.precision == PD_PREC_F16 ? DT_F16 : DT_BF16;
+    P = cfg.precision == PD_PREC_F16X2 ? PREC_F16X2 : T;
+    S = (f32 || cfg.stream_f32) ? DT_F32 : T;
     if (cfg.model_channels % 32 || cfg.num_levels < 1 || cfg.num_levels > PD_MAX_LEVELS || cfg.num_heads < 1) {
         pd_set_error("unsupported config: model_channels must be a multiple of 32, 1..%d levels", PD_MAX_LEVELS);
         return 1;
@@ -337,6 +342,29 @@ static inline uint16_t host_f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+// fp32 -> fp16, round to nearest even (overflow -> inf, subnormals kept), NaN stays NaN
+static inline uint16_t host_f2h(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          // >= 65520 rounds to inf
+    if (u < 0x38800000u) {                                            // subnormal half (or zero)
+        if (u < 0x33000000u) return sign;                             // < 2^-25 rounds to zero
+        const int shift = 113 - (int)(u >> 23);                       // 1..24
+        uint32_t man = (u & 0x7fffffu) | 0x800000u;
+        const uint32_t half = 1u << (shift + 12), rest = man & ((half << 1) - 1);
+        man >>= shift + 13;
+        if (rest > half || (rest == half && (man & 1u))) ++man;
+        return (uint16_t)(sign | man);
+    }
+    uint32_t r = u - 0x38000000u;                                     // rebias exponent
+    const uint32_t rest = r & 0x1fffu;
+    r >>= 13;
+    if (rest > 0x1000u || (rest == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
 static inline float host_h2f(uint16_t h) {
     const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
     uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff, u;
@@ -438,7 +466,7 @@ int pd_engine::upload_rows(WMat& m, int row_off, const float* src, int rows, boo
                 const float v = conv ? src[((size_t)r * cin + c) * kk + tp] : src[(size_t)r * cin + c];
                 const size_t k = (size_t)tp * m.cin_pad + c;
                 if (EB == 4) reinterpret_cast<float*>(drow)[k] = v;
-                else reinterpret_cast<uint16_t*>(drow)[k] = host_f2bf(v);
+                else reinterpret_cast<uint16_t*>(drow)[k] = T == DT_F16 ? host_f2h(v) : host_f2bf(v);
             }
     }
     const size_t rowb = (size_t)m.Kpad * EB;
@@ -545,9 +573,8 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.slab = nullptr;
     p.gn_coef = gn_coef;
     p.gn_silu = gn_silu ? 1 : 0;
-    p.diag = opt_diag;
     // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
-    const int ptiles = opt_patch ? conv_patch_tiles(p, f32) : 0;
+    const int ptiles = opt_patch ? conv_patch_tiles(p, P) : 0;
     bool use_patch = ptiles >= 192;
     // 16x16-level convs: too few 16x16 patches for the chip, but the patch kernel still beats the generic gather when the
     // channel chunks are split across 2-4 slices (fp32 slabs + the same deterministic finalize pass as the GEMM's split-K)
@@ -569,12 +596,9 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         const int tiles = gemm_tiles(p.M, m.N);
         const int ktiles = m.Kpad / (128 / (int)dt_size(T));
         int splitk = 1;
-        // big linear layers: 256 x 256 LDS-DMA tile (gemm8.hip) when it still gives every CU a block
-        const bool use8 = opt_gemm8 && !f32 && gemm8_eligible(p) &&
-                          ((p.M + 255) / 256) * ((m.N + 255) / 256) >= opt_gemm8_tiles;
         // linear layers with a short K and at least half a chip of tiles: one 8-wave block per CU instead of split-K
-        const bool dense8 = !use8 && opt_dense_k > 0 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
-        if (!use8 && !dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
+        const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
+        if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
             splitk = (512 + tiles - 1) / tiles;
             if (splitk > ktiles / 8) splitk = ktiles / 8;
             if (splitk > opt_splitk_max) splitk = opt_splitk_max;
@@ -599,7 +623,6 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         // stores of one tile overlapping the MFMAs of others, i.e. many waves per CU rather than a big tile -- the
         // 128 x 160 tile on 8 waves at <= 128 VGPRs runs 2 blocks = 16 waves per CU (+0.6 % end-to-end, interleaved A/B)
         if (opt_short_k > 0 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_short_k) p.big_tile = 2;
-        if (use8) p.big_tile = 4;
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
     }
     if (use_patch && patch_split > 1) {
@@ -623,11 +646,9 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = p.taps * 10 + p.stride + (p.ups ? 5 : 0);
     }
     hipEvent_t mid = nullptr;
-    const bool use8 = !use_patch && p.big_tile == 4;
-    if (use8) ++gemm8_launches;
-    if (profiling && !use_patch && !use8) { mid = next_event(); rec.klass = m.taps == 9 ? 0 : 1; }
+    if (profiling && !use_patch) { mid = next_event(); rec.klass = m.taps == 9 ? 0 : 1; }
     if (profiling && use_patch) rec.klass = 3;
-    if (use_patch ? launch_conv_patch(p, f32, stream) : use8 ? launch_gemm8(p, stream) : launch_gemm(p, f32, stream, mid)) {
+    if (use_patch ? launch_conv_patch(p, P, stream) : launch_gemm(p, P, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;
     }
@@ -686,7 +707,7 @@ int pd_engine::conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, c
     GemmParams q{};
     q.M = (int)out.rows(); q.N = c.m.N; q.K = c.m.K; q.taps = c.m.taps; q.Cin = c.m.cin_pad; q.stride = c.stride;
     q.Hin = x.H; q.Win = x.W; q.Hout = out.H; q.Wout = out.W; q.a_dt = x.dt; q.vt_begin = INT_MAX; q.splitk = 1;
-    const bool fuse = opt_gn_fuse && opt_patch && x.C == c.m.cin_pad && conv_patch_tiles(q, f32) >= 192;
+    const bool fuse = opt_gn_fuse && opt_patch && x.C == c.m.cin_pad && conv_patch_tiles(q, P) >= 192;
     if (!fuse) {
         const size_t mk = arena.mark();
         Act a = new_act(x.B, x.H, x.W, x.C, T);
@@ -743,7 +764,7 @@ int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const v
         prof_begin(rec, 2, 4.0 * (double)B * heads * (double)Nq * (double)Nk * (double)p.dh);
         rec.M = Nq; rec.N = Nk; rec.K = p.dh; rec.taps = B;
     }
-    const int r = launch_attention(p, f32, stream);
+    const int r = launch_attention(p, P, stream);
     if (profiling) prof_end(rec);
     if (r) {
         pd_set_error(r == 2 ? "attention: unsupported head dim %d" : "attention launch failed (dh %d)", p.dh);

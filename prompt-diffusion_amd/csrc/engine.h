@@ -198,9 +198,10 @@ struct pd_engine {
     pd_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    bool f32 = false;
-    int T = DT_BF16;  // compute (MFMA operand) type
-    int S = DT_BF16;  // residual-stream type
+    bool f32 = false;   // fp32 storage of activations and weights (PD_PREC_F32 and PD_PREC_F16X2)
+    int P = DT_BF16;    // MFMA precision code handed to the contraction launchers: T, or PREC_F16X2
+    int T = DT_BF16;  // compute (MFMA operand) type: DT_BF16, DT_F16 or DT_F32
+    int S = DT_BF16;  // residual-stream type: T, or DT_F32 with stream_f32
     std::vector<Param> params;
     std::unordered_map<std::string, int> index;
     NetW unet, cnet;
@@ -231,7 +232,6 @@ struct pd_engine {
     int opt_splitk_max = 8;
     int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
-    int opt_diag = 0;          // timing diagnostic (wrong results): GEMM operands all read row 0
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
     int opt_dense_tiles = 128;
     bool opt_gn_single = true; // GroupNorm as one LDS-slab kernel where a sample's group bundle fits (32x32 and below)
@@ -240,9 +240,6 @@ struct pd_engine {
     bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
     int opt_patch_split_tiles = 64;
     int opt_patch_split_fill = 256;   // slices are chosen to reach about this many blocks
-    bool opt_gemm8 = false;    // 256 x 256 LDS-DMA tile kernel for big bf16 linear layers
-    int opt_gemm8_tiles = 256;
-    long long gemm8_launches = 0;
     int opt_dense_k = 40;      // linear layers with at most this many K steps and >= opt_dense_tiles tiles: one 8-wave block per CU, no split-K
     bool opt_bigtile = true;  // 256-row GEMM tiles where the grid still fills the chip
     // apply GroupNorm(+SiLU) inside the patch conv's staging.  Measured neutral-to-negative in round 1 (the SiLU VALU work

@@ -35,13 +35,14 @@ constexpr int BKB = 128;  // bytes of K per LDS row
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row * BKB) + (((chunk ^ (row >> 1)) & 7) << 4); }
 
-// F32: fp32 MFMA mode.  CONV: 3x3 gather (else rows of A are contiguous).  AF32: bf16 compute with an
-// fp32 A source (converted while staging; only meaningful when !F32).
-template <bool F32, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
+// P: compute type (DT_F32: fp32 MFMA mode; DT_BF16 / DT_F16: 2-byte operands).  CONV: 3x3 gather (else rows of A
+// are contiguous).  AF32: 2-byte compute with an fp32 A source (converted while staging; only meaningful when P != DT_F32).
+template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) void igemm_kernel(GemmParams p) {
+    constexpr bool F32 = prec_f32_storage(P);
     // register prefetch depth: two K steps ahead (two named staging sets) unless the fp32->bf16 staging
     // path already doubles the A registers
-    constexpr int DEPTH = (AF32 || BN > 160 || (BM == 128 && WM * WN == 8)) ? 1 : 2;   // the 16-waves-per-CU shape has 128 VGPRs per wave
+    constexpr int DEPTH = (AF32 || BN > 160 || (BM == 128 && WM * WN == 8) || P == PREC_F16X2) ? 1 : 2;   // the 16-waves-per-CU shape has 128 VGPRs per wave
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int A_ITERS = BM * 8 / NTHREADS;                   // 16-byte chunks per thread per K step
     constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;  // last one masked when it does not divide
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             a_x[i] = (rem - oy * p.Wout) * p.stride - 1;
             a_base[i] = 0;
         } else {
-            a_base[i] = (size_t)(p.diag ? 0 : mm) * p.lda;
+            a_base[i] = (size_t)mm * p.lda;
             a_pix[i] = a_y[i] = a_x[i] = 0;
         }
     }
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     for (int i = 0; i < B_ITERS; ++i) {
         int n = bn * BN + row0 + ROWS_PER_IT * i;
         n = n < p.N ? n : p.N - 1;  // clamp: columns >= N are never stored
-        w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)(p.diag ? 0 : n) * (p.ldw ? p.ldw : p.Kpad) + chunk * VEC) * EB;
+        w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)n * (p.ldw ? p.ldw : p.Kpad) + chunk * VEC) * EB;
     }
 
     const int ktiles_all = p.Kpad / BKE;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
                     for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
                 }
             } else if constexpr (AF32) {
-                v = cvt8(RA(S, I), RH(I), p.a_silu != 0);
+                v = cvt8<P>(RA(S, I), RH(I), p.a_silu != 0);
             } else {
                 v = RA(S, I);
             }
@@ -221,15 +222,16 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
         const char* sb = sa + BM * BKB;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 af[MT], wf[NT];
+            typename Frag<P>::A af[MT];
+            typename Frag<P>::W wf[NT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, ks * 4 + fq));
+            for (int m = 0; m < MT; ++m) af[m] = prep_a<P>(*reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, ks * 4 + fq)));
 #pragma unroll
-            for (int n = 0; n < NT; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, ks * 4 + fq));
+            for (int n = 0; n < NT; ++n) wf[n] = prep_w<P>(*reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, ks * 4 + fq)));
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) mma<F32>(wf[n], af[m], acc[n][m]);
+                for (int m = 0; m < MT; ++m) mma<P>(wf[n], af[m], acc[n][m]);
         }
     };
     using S0 = std::integral_constant<int, 0>;
@@ -390,18 +392,13 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
     }
 }
 
-template <bool F32, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
+template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
 int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB;
-    static bool attr_done = false;
-    auto kfn = igemm_kernel<F32, BM, BN, WM, WN, CONV, AF32>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SMEM_BYTES) != hipSuccess)
-            return 1;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;
+    auto kfn = igemm_kernel<P, BM, BN, WM, WN, CONV, AF32>;
+    if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM_BYTES, &attr_done)) return 1;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
     dim3 grid(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, s, p);
@@ -430,28 +427,44 @@ int launch_splitk_finalize(const GemmParams& p, hipStream_t s) {
 
 int gemm_tiles(int M, int N) { return ((M + 127) / 128) * ((N + 159) / 160); }
 
-int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid) {
-    if (p.M <= 0 || p.N <= 0) return 0;
+namespace {
+template <int P>
+int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
+    constexpr bool F = prec_f32_storage(P);
     const bool conv = p.taps != 1;
-    const bool af32 = p.a_dt == DT_F32;
-    if (p.splitk > 1 && (p.act == 2 || p.vt_begin < p.N || !p.slab || p.N % 4)) return 1;
+    const bool af32 = !F && p.a_dt == DT_F32;          // 2-byte compute reading an fp32 A (converted while staging)
     const int tile = p.splitk == 1 ? p.big_tile : 0;   // 0: 128x160, 1: 256x160, 2: 128x160 on 8 waves, 3: 256x320
     if (p.act == 2) {
-        if (conv || (!f32mode && af32)) return 1;
-        if (tile == 3) return f32mode ? launch_one<true, 256, 320, 8, 1, false, false>(p, s, mid) : launch_one<false, 256, 320, 8, 1, false, false>(p, s, mid);
-        if (tile == 1) return f32mode ? launch_one<true, 256, 160, 8, 1, false, false>(p, s, mid) : launch_one<false, 256, 160, 8, 1, false, false>(p, s, mid);
-        return f32mode ? launch_one<true, 128, 160, 4, 1, false, false>(p, s, mid) : launch_one<false, 128, 160, 4, 1, false, false>(p, s, mid);
+        if (conv || af32) return 1;
+        if (tile == 3) return launch_one<P, 256, 320, 8, 1, false, false>(p, s, mid);
+        if (tile == 1) return launch_one<P, 256, 160, 8, 1, false, false>(p, s, mid);
+        return launch_one<P, 128, 160, 4, 1, false, false>(p, s, mid);
     }
-    if (tile == 3 && !conv && !af32)
-        return f32mode ? launch_one<true, 256, 320, 4, 2, false, false>(p, s, mid) : launch_one<false, 256, 320, 4, 2, false, false>(p, s, mid);
-    if (tile == 2 && !conv && !af32)
-        return f32mode ? launch_one<true, 128, 160, 4, 2, false, false>(p, s, mid) : launch_one<false, 128, 160, 4, 2, false, false>(p, s, mid);
-    if (tile == 1 || tile == 3) {
-        if (f32mode) return conv ? launch_one<true, 256, 160, 4, 2, true, false>(p, s, mid) : launch_one<true, 256, 160, 4, 2, false, false>(p, s, mid);
-        if (conv) return af32 ? launch_one<false, 256, 160, 4, 2, true, true>(p, s, mid) : launch_one<false, 256, 160, 4, 2, true, false>(p, s, mid);
-        return af32 ? launch_one<false, 256, 160, 4, 2, false, true>(p, s, mid) : launch_one<false, 256, 160, 4, 2, false, false>(p, s, mid);
+    if constexpr (F) {   // fp32 mode: the 128x160 / 256x160 four-wave-group tiles only
+        if (tile == 1 || tile == 3) return conv ? launch_one<P, 256, 160, 4, 2, true, false>(p, s, mid) : launch_one<P, 256, 160, 4, 2, false, false>(p, s, mid);
+        return conv ? launch_one<P, 128, 160, 2, 2, true, false>(p, s, mid) : launch_one<P, 128, 160, 2, 2, false, false>(p, s, mid);
+    } else {
+        if (tile == 3 && !conv && !af32) return launch_one<P, 256, 320, 4, 2, false, false>(p, s, mid);
+        if (tile == 2 && !conv && !af32) return launch_one<P, 128, 160, 4, 2, false, false>(p, s, mid);
+        if (tile == 1 || tile == 3) {
+            if (conv) return af32 ? launch_one<P, 256, 160, 4, 2, true, true>(p, s, mid) : launch_one<P, 256, 160, 4, 2, true, false>(p, s, mid);
+            return af32 ? launch_one<P, 256, 160, 4, 2, false, true>(p, s, mid) : launch_one<P, 256, 160, 4, 2, false, false>(p, s, mid);
+        }
+        if (conv) return af32 ? launch_one<P, 128, 160, 2, 2, true, true>(p, s, mid) : launch_one<P, 128, 160, 2, 2, true, false>(p, s, mid);
+        return af32 ? launch_one<P, 128, 160, 2, 2, false, true>(p, s, mid) : launch_one<P, 128, 160, 2, 2, false, false>(p, s, mid);
     }
-    if (f32mode) return conv ? launch_one<true, 128, 160, 2, 2, true, false>(p, s, mid) : launch_one<true, 128, 160, 2, 2, false, false>(p, s, mid);
-    if (conv) return af32 ? launch_one<false, 128, 160, 2, 2, true, true>(p, s, mid) : launch_one<false, 128, 160, 2, 2, true, false>(p, s, mid);
-    return af32 ? launch_one<false, 128, 160, 2, 2, false, true>(p, s, mid) : launch_one<false, 128, 160, 2, 2, false, false>(p, s, mid);
+}
+}  // namespace
+
+int launch_gemm(const GemmParams& p, int prec, hipStream_t s, hipEvent_t mid) {
+    if (p.M <= 0 || p.N <= 0) return 0;
+    if (p.splitk > 1 && (p.act == 2 || p.vt_begin < p.N || !p.slab || p.N % 4)) return 1;
+    if (prec_f32_storage(prec) ? p.a_dt != DT_F32 : (p.a_dt != DT_F32 && p.a_dt != prec)) return 1;   // operand type must match the mode
+    switch (prec) {
+        case DT_F32: return launch_prec<DT_F32>(p, s, mid);
+        case PREC_F16X2: return launch_prec<PREC_F16X2>(p, s, mid);
+        case DT_BF16: return launch_prec<DT_BF16>(p, s, mid);
+        case DT_F16: return launch_prec<DT_F16>(p, s, mid);
+        default: return 1;
+    }
 }

@@ -7,15 +7,18 @@
 //              coalesced sweep writes (x-mean)*rstd*gamma+beta (optionally SiLU'd) in the compute type.
 // LayerNorm (nn.LayerNorm, eps 1e-5, attention.py:263-265): one wave per token row, row held in
 // registers, two-pass variance in fp32.
+#include <type_traits>
+
 #include "pd_common.h"
 
 namespace {
 
 constexpr int GN_THREADS = 256;
 
-template <bool XF32>
+template <int XD>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const void* __restrict__ x, double* __restrict__ partial,
                                                                int HW, int C, int groups, int nchunk) {
+    constexpr bool XF32 = XD == DT_F32;
     constexpr int VEC = XF32 ? 4 : 8;
     __shared__ double s_sum[64], s_sq[64];
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -47,12 +50,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const void* __rest
                     for (int j = 0; j < 4; ++j) f[j] = t[j];
                 } else {
                     const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + idx);
-                    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f[2 * j] = __uint_as_float(w[j] << 16);
-                        f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
-                    }
+                    unpack8<XD>(t, f);
                 }
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
@@ -83,12 +81,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const void* __rest
 // y = x * a[c] + b[c] with a = rstd[g] * gamma[c], b = beta[c] - mean[g] * a: each thread owns one 16-byte
 // channel vector (its a/b live in registers) and walks the pixels of the block's slab -- no integer
 // division or per-element group lookup in the loop.
-template <bool XF32, bool YF32>
+template <int XD, int YD>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                                const double* __restrict__ partial,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                int HW, int C, int groups, int nchunk, int napply,
                                                                float eps, int do_silu) {
+    constexpr bool XF32 = XD == DT_F32, YF32 = YD == DT_F32;
     constexpr int VEC = XF32 ? 4 : 8;  // elements per 16-byte input vector
     __shared__ float s_mean[64], s_rstd[64];
     const int b = blockIdx.y;
@@ -136,12 +135,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) f[j] = t[j];
             } else {
-                const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f[2 * j] = __uint_as_float(w[j] << 16);
-                    f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
-                }
+                unpack8<XD>(raw, f);
             }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -155,12 +149,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
             } else {
                 uint16_t* o = reinterpret_cast<uint16_t*>(yb) + e;
                 if constexpr (VEC == 8) {
-                    uint4 u;
-                    u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
-                    *reinterpret_cast<uint4*>(o) = u;
+                    *reinterpret_cast<uint4*>(o) = pack8<YD>(f);
                 } else {
                     uint2 u;
-                    u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]);
+                    u.x = pack2<YD>(f[0], f[1]); u.y = pack2<YD>(f[2], f[3]);
                     *reinterpret_cast<uint2*>(o) = u;
                 }
             }
@@ -174,10 +166,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
 // normalises out of LDS.  One read + one write of the tensor and one launch instead of two reads + one write in two.
 constexpr int GNF_THREADS = 960;   // 15 waves; divisible by 5, 10, 15 (vectors per pixel of the bundles that occur)
 
-template <bool XF32, bool YF32>
+template <int XD, int YD>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 int HW, int C, int groups, int BC, float eps, int do_silu) {
+    constexpr bool XF32 = XD == DT_F32, YF32 = YD == DT_F32;
     constexpr int VEC = XF32 ? 4 : 8;
     constexpr int EX = XF32 ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) char slab[];   // [HW][BC] raw input, then [waves][4][2] doubles
@@ -213,9 +206,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) f[j] = t[j];
         } else {
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+            unpack8<XD>(raw, f);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
@@ -273,9 +264,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) f[j] = t[j];
         } else {
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+            unpack8<XD>(raw, f);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -289,12 +278,10 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __res
         } else {
             uint16_t* o = reinterpret_cast<uint16_t*>(yb + (size_t)p * C * 2);
             if constexpr (VEC == 8) {
-                uint4 u;
-                u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
-                *reinterpret_cast<uint4*>(o) = u;
+                *reinterpret_cast<uint4*>(o) = pack8<YD>(f);
             } else {
                 uint2 u;
-                u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]);
+                u.x = pack2<YD>(f[0], f[1]); u.y = pack2<YD>(f[2], f[3]);
                 *reinterpret_cast<uint2*>(o) = u;
             }
         }
@@ -333,7 +320,7 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__
 }
 
 // one wave per row; C <= 64*MAXV*4
-template <bool XF32, bool YF32, int MAXV>
+template <int XD, int YD, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int rows, int C, float eps) {
@@ -347,7 +334,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     for (int k = 0; k < MAXV; ++k) {
         const int vi = lane + 64 * k;
         if (vi < nvec4) {
-            v[k] = load4(x, (size_t)row * C + (size_t)vi * 4, XF32 ? DT_F32 : DT_BF16);
+            v[k] = load4(x, (size_t)row * C + (size_t)vi * 4, XD);
             s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
         } else {
             v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -377,9 +364,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[k][j] - mean) * rstd * g[j] + be[j];
-            store4(y, (size_t)row * C + (size_t)vi * 4, YF32 ? DT_F32 : DT_BF16, o);
+            store4(y, (size_t)row * C + (size_t)vi * 4, YD, o);
         }
     }
+}
+
+// calls f(integral_constant<XD>, integral_constant<YD>) for the (input, output) type pairs the engine produces:
+// fp32 on either side, or the same 2-byte flavour on both
+template <typename F>
+bool dispatch_xy(int x_dt, int y_dt, F&& f) {
+    using IF = std::integral_constant<int, DT_F32>;
+    using IB = std::integral_constant<int, DT_BF16>;
+    using IH = std::integral_constant<int, DT_F16>;
+    if (x_dt == DT_F32 && y_dt == DT_F32) f(IF{}, IF{});
+    else if (x_dt == DT_F32 && y_dt == DT_BF16) f(IF{}, IB{});
+    else if (x_dt == DT_F32 && y_dt == DT_F16) f(IF{}, IH{});
+    else if (x_dt == DT_BF16 && y_dt == DT_F32) f(IB{}, IF{});
+    else if (x_dt == DT_F16 && y_dt == DT_F32) f(IH{}, IF{});
+    else if (x_dt == DT_BF16 && y_dt == DT_BF16) f(IB{}, IB{});
+    else if (x_dt == DT_F16 && y_dt == DT_F16) f(IH{}, IH{});
+    else return false;
+    return true;
 }
 
 }  // namespace
@@ -388,9 +393,11 @@ int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int
     if (groups > 64 || C % groups || C % 8) return 1;
     dim3 grid(nchunk, B);
     if (x_dt == DT_F32)
-        hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_THREADS), 0, s, x, partial, HW, C, groups, nchunk);
+        hipLaunchKernelGGL(gn_stats_kernel<DT_F32>, grid, dim3(GN_THREADS), 0, s, x, partial, HW, C, groups, nchunk);
+    else if (x_dt == DT_F16)
+        hipLaunchKernelGGL(gn_stats_kernel<DT_F16>, grid, dim3(GN_THREADS), 0, s, x, partial, HW, C, groups, nchunk);
     else
-        hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_THREADS), 0, s, x, partial, HW, C, groups, nchunk);
+        hipLaunchKernelGGL(gn_stats_kernel<DT_BF16>, grid, dim3(GN_THREADS), 0, s, x, partial, HW, C, groups, nchunk);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -401,15 +408,11 @@ int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* pa
     if (napply > HW / 4) napply = HW / 4;
     if (napply < 1) napply = 1;
     dim3 grid(napply, B);
-#define GN_AP(XF, YF)                                                                                                 \
-    hipLaunchKernelGGL((gn_apply_kernel<XF, YF>), grid, dim3(GN_THREADS), 0, s, x, y, partial, gamma, beta, HW, C, \
-                       groups, nchunk, napply, eps, silu)
-    if (x_dt == DT_F32 && y_dt == DT_F32) GN_AP(true, true);
-    else if (x_dt == DT_F32) GN_AP(true, false);
-    else if (y_dt == DT_F32) GN_AP(false, true);
-    else GN_AP(false, false);
-#undef GN_AP
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    const bool ok = dispatch_xy(x_dt, y_dt, [&](auto XD, auto YD) {
+        hipLaunchKernelGGL((gn_apply_kernel<decltype(XD)::value, decltype(YD)::value>), grid, dim3(GN_THREADS), 0, s, x, y, partial,
+                           gamma, beta, HW, C, groups, nchunk, napply, eps, silu);
+    });
+    return ok && hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 // bundle width (channels) for gn_fused_kernel, or 0 when the shape is not eligible (slab beyond the LDS budget)
@@ -431,20 +434,14 @@ int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gam
     const int EX = x_dt == DT_F32 ? 4 : 2;
     const size_t smem = (size_t)HW * BC * EX + (GNF_THREADS / 64) * 4 * 2 * sizeof(double);
     const dim3 grid(B * (C / BC));
-#define GNF(XF, YF)                                                                                                        \
-    do {                                                                                                                   \
-        static bool attr_done = false;                                                                                     \
-        auto kfn = gn_fused_kernel<XF, YF>;                                                                                \
-        if (!attr_done) {                                                                                                  \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024) != hipSuccess) return 1; \
-            attr_done = true;                                                                                              \
-        }                                                                                                                  \
-        hipLaunchKernelGGL(kfn, grid, dim3(GNF_THREADS), smem, s, x, y, gamma, beta, HW, C, groups, BC, eps, do_silu);      \
-    } while (0)
-    const bool xf = x_dt == DT_F32, yf = y_dt == DT_F32;
-    if (xf && yf) GNF(true, true); else if (xf) GNF(true, false); else if (yf) GNF(false, true); else GNF(false, false);
-#undef GNF
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    bool fail = false;
+    const bool ok = dispatch_xy(x_dt, y_dt, [&](auto XD, auto YD) {
+        static unsigned long long attr_done = 0;   // one per (XD, YD) instantiation of this lambda
+        auto kfn = gn_fused_kernel<decltype(XD)::value, decltype(YD)::value>;
+        if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), 104 * 1024, &attr_done)) { fail = true; return; }
+        hipLaunchKernelGGL(kfn, grid, dim3(GNF_THREADS), smem, s, x, y, gamma, beta, HW, C, groups, BC, eps, do_silu);
+    });
+    return ok && !fail && hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int launch_gn_coef(const double* partial, const float* gamma, const float* beta, float* coef, int B, int HW, int C, int groups,
@@ -457,20 +454,12 @@ int launch_layernorm(const void* x, int x_dt, void* y, int y_dt, const float* ga
                      int C, float eps, hipStream_t s) {
     if (C % 4 || C > 64 * 4 * 8) return 1;
     dim3 grid((rows + 3) / 4);
-#define LN_L(XF, YF, MV)                                                                                       \
-    hipLaunchKernelGGL((layernorm_kernel<XF, YF, MV>), grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps)
-#define LN_D(MV)                                                  \
-    do {                                                          \
-        if (x_dt == DT_F32 && y_dt == DT_F32) LN_L(true, true, MV);   \
-        else if (x_dt == DT_F32) LN_L(true, false, MV);           \
-        else if (y_dt == DT_F32) LN_L(false, true, MV);           \
-        else LN_L(false, false, MV);                              \
-    } while (0)
     const int nv = (C / 4 + 63) / 64;
-    if (nv <= 2) LN_D(2);
-    else if (nv <= 5) LN_D(5);
-    else LN_D(8);
-#undef LN_D
-#undef LN_L
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    const bool ok = dispatch_xy(x_dt, y_dt, [&](auto XD, auto YD) {
+        constexpr int xd = decltype(XD)::value, yd = decltype(YD)::value;
+        if (nv <= 2) hipLaunchKernelGGL((layernorm_kernel<xd, yd, 2>), grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+        else if (nv <= 5) hipLaunchKernelGGL((layernorm_kernel<xd, yd, 5>), grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<xd, yd, 8>), grid, dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+    });
+    return ok && hipGetLastError() == hipSuccess ? 0 : 1;
 }

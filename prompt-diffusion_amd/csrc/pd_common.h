@@ -4,12 +4,20 @@
 #include <stdint.h>
 #include <stddef.h>
 
-enum PdDType : int { DT_F32 = 0, DT_BF16 = 1 };
+// Storage / MFMA operand types.  DT_BF16 and DT_F16 share one byte-level data path (2-byte elements); the engine's
+// compute type T is one of the three and selects the MFMA instruction and the converts.
+enum PdDType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 static inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+// MFMA precision codes handed to the contraction launchers: the operand PdDType, or PREC_F16X2 -- fp32 storage like
+// DT_F32, but every operand is split into fp16 hi + lo halves in registers and the product runs as two fp16 MFMAs
+// (all four hi/lo cross terms): ~22-bit operands at a quarter of the fp16 MFMA rate, 4x the fp32 MFMA rate.
+constexpr int PREC_F16X2 = 3;
+constexpr bool prec_f32_storage(int P) { return P == DT_F32 || P == PREC_F16X2; }
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -23,6 +31,43 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     // one v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) instead of two converts + shift + or
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // v_cvt_f16_f32, RNE
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+// 16-bit flavour helpers: DT is DT_BF16 or DT_F16 (compile-time in the kernels that are templated on it)
+template <int DT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (DT == DT_F16) return pack2h(lo, hi); else return pack2bf(lo, hi);
+}
+template <int DT> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+    if constexpr (DT == DT_F16) {
+        const f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+        lo = (float)h[0]; hi = (float)h[1];
+    } else {
+        lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+    }
+}
+template <int DT> __device__ __forceinline__ uint16_t cvt16(float f) {
+    if constexpr (DT == DT_F16) return f2h(f); else return f2bf(f);
+}
+template <int DT> __device__ __forceinline__ float cvt32(uint16_t v) {
+    if constexpr (DT == DT_F16) return h2f(v); else return bf2f(v);
+}
+// runtime-tagged forms (dt is wave-uniform: a kernel argument)
+__device__ __forceinline__ uint16_t cvt16_rt(float f, int dt) { return dt == DT_F16 ? f2h(f) : f2bf(f); }
+__device__ __forceinline__ float cvt32_rt(uint16_t v, int dt) { return dt == DT_F16 ? h2f(v) : bf2f(v); }
+// 8 packed 16-bit values (one uint4) <-> 8 floats
+template <int DT> __device__ __forceinline__ void unpack8(const uint4& r, float* f) {
+    unpack2<DT>(r.x, f[0], f[1]); unpack2<DT>(r.y, f[2], f[3]); unpack2<DT>(r.z, f[4], f[5]); unpack2<DT>(r.w, f[6], f[7]);
+}
+template <int DT> __device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 u;
+    u.x = pack2<DT>(f[0], f[1]); u.y = pack2<DT>(f[2], f[3]); u.z = pack2<DT>(f[4], f[5]); u.w = pack2<DT>(f[6], f[7]);
+    return u;
 }
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     float r;  // single instruction: hipcc otherwise canonicalises MFMA outputs with extra v_max before fmaxf
@@ -52,10 +97,15 @@ __device__ __forceinline__ f32x4 load4(const void* base, size_t idx, int dt) {
         r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
     } else {
         uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
-        r[0] = __uint_as_float(u.x << 16);
-        r[1] = __uint_as_float(u.x & 0xffff0000u);
-        r[2] = __uint_as_float(u.y << 16);
-        r[3] = __uint_as_float(u.y & 0xffff0000u);
+        float a, b, c, d;
+        if (dt == DT_F16) {
+            unpack2<DT_F16>(u.x, a, b);
+            unpack2<DT_F16>(u.y, c, d);
+        } else {
+            unpack2<DT_BF16>(u.x, a, b);
+            unpack2<DT_BF16>(u.y, c, d);
+        }
+        r = f32x4{a, b, c, d};
     }
     return r;
 }
@@ -64,12 +114,29 @@ __device__ __forceinline__ void store4(void* base, size_t idx, int dt, f32x4 v) 
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v;
     } else {
         uint2 u;
-        u.x = pack2bf(v[0], v[1]);
-        u.y = pack2bf(v[2], v[3]);
+        if (dt == DT_F16) {
+            u.x = pack2h(v[0], v[1]);
+            u.y = pack2h(v[2], v[3]);
+        } else {
+            u.x = pack2bf(v[0], v[1]);
+            u.y = pack2bf(v[2], v[3]);
+        }
         *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + idx) = u;
     }
 }
 #endif
+
+// One-time (per device) opt-in to more than 64 KB of dynamic LDS for a kernel.  `done` is a static bit mask owned by the
+// launcher (one bit per device id: engines on different devices share the process).
+static inline int ensure_dyn_smem(const void* fn, int bytes, unsigned long long* done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (*done & bit) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return 1;
+    *done |= bit;
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution / linear:  C[M,N] = epilogue( A_gather[M,K] x W[N,K]^T )
@@ -103,7 +170,6 @@ struct GemmParams {
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;
     int ldw;              // weight row stride in elements (0: Kpad) -- lets a device activation act as the W operand
-    int diag;             // timing diagnostic: every tile row reads row 0 (operands served from L1); results are wrong
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
@@ -119,14 +185,12 @@ struct AttnParams {
     int causal;  // keys after the query are masked (CLIP text transformer)
 };
 
-int launch_gemm(const GemmParams& p, bool f32mode, hipStream_t s, hipEvent_t mid = nullptr);
+int launch_gemm(const GemmParams& p, int prec, hipStream_t s, hipEvent_t mid = nullptr);   // prec: the compute type (DT_*)
 int gemm_tiles(int M, int N);
 int launch_splitk_finalize(const GemmParams& p, hipStream_t s);   // sums p.splitk fp32 slabs in slice order + epilogue
-int conv_patch_tiles(const GemmParams& p, bool f32mode);  // 0: shape not eligible for the LDS-patch conv kernel
-int launch_conv_patch(const GemmParams& p, bool f32mode, hipStream_t s);
-bool gemm8_eligible(const GemmParams& p);          // gemm8.hip: 256 x 256 LDS-DMA tile, bf16 linear layers
-int launch_gemm8(const GemmParams& p, hipStream_t s);
-int launch_attention(const AttnParams& p, bool f32mode, hipStream_t s);
+int conv_patch_tiles(const GemmParams& p, int prec);  // 0: shape not eligible for the LDS-patch conv kernel
+int launch_conv_patch(const GemmParams& p, int prec, hipStream_t s);
+int launch_attention(const AttnParams& p, int prec, hipStream_t s);
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
                     const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s);

@@ -15,20 +15,71 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <bool F32>
-__device__ __forceinline__ void mma(const uint4& w, const uint4& a, f32x4& acc) {
-    if constexpr (F32) {
+// MFMA operand fragments.  For the plain modes a fragment is the 16 bytes read from LDS.  PREC_F16X2 converts the
+// 4 floats of a fragment once per K step: A -> [hi0..3 | lo0..3] (8 halfs), W -> {[hi|hi], [lo|lo]}; two
+// v_mfma_f32_16x16x32_f16 then sum wh*ah + wh*al + wl*ah + wl*al.  hi is the truncated value (v_cvt_pkrtz), so
+// x - hi is exact in fp32 and lo carries the next 11 bits.
+struct FragW2 { uint4 hi, lo; };
+template <int P> struct Frag { using A = uint4; using W = uint4; };
+template <> struct Frag<PREC_F16X2> { using A = uint4; using W = FragW2; };
+
+__device__ __forceinline__ void split_f16(const uint4& v, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
+    const float* f = reinterpret_cast<const float*>(&v);
+    const auto a = __builtin_amdgcn_cvt_pkrtz(f[0], f[1]);
+    const auto b = __builtin_amdgcn_cvt_pkrtz(f[2], f[3]);
+    h01 = __builtin_bit_cast(uint32_t, a);
+    h23 = __builtin_bit_cast(uint32_t, b);
+    l01 = pack2h(f[0] - (float)a[0], f[1] - (float)a[1]);
+    l23 = pack2h(f[2] - (float)b[0], f[3] - (float)b[1]);
+}
+template <int P> __device__ __forceinline__ typename Frag<P>::A prep_a(const uint4& v) {
+    if constexpr (P == PREC_F16X2) {
+        uint4 r;
+        split_f16(v, r.x, r.y, r.z, r.w);
+        return r;
+    } else {
+        return v;
+    }
+}
+template <int P> __device__ __forceinline__ typename Frag<P>::W prep_w(const uint4& v) {
+    if constexpr (P == PREC_F16X2) {
+        uint32_t h01, h23, l01, l23;
+        split_f16(v, h01, h23, l01, l23);
+        FragW2 r;
+        r.hi = make_uint4(h01, h23, h01, h23);
+        r.lo = make_uint4(l01, l23, l01, l23);
+        return r;
+    } else {
+        return v;
+    }
+}
+
+// one 16x16 MFMA step over a 16-byte K fragment of each operand; P = DT_F32 / DT_BF16 / DT_F16 / PREC_F16X2
+template <int P>
+__device__ __forceinline__ void mma(const typename Frag<P>::W& w, const typename Frag<P>::A& a, f32x4& acc) {
+    if constexpr (P == DT_F32) {
         const float* wf = reinterpret_cast<const float*>(&w);
         const float* af = reinterpret_cast<const float*>(&a);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[j], acc, 0, 0, 0);
+    } else if constexpr (P == PREC_F16X2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w.hi), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w.lo), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+    } else if constexpr (P == DT_F16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
     } else {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a),
                                                       acc, 0, 0, 0);
     }
 }
+// the same from two raw 16-byte fragments (converts per call in PREC_F16X2: attention only)
+template <int P>
+__device__ __forceinline__ void mma_raw(const uint4& w, const uint4& a, f32x4& acc) {
+    mma<P>(prep_w<P>(w), prep_a<P>(a), acc);
+}
 
-// convert 8 fp32 (two uint4) to 8 bf16 (one uint4)
+// convert 8 fp32 (two uint4) to 8 bf16 / fp16 (one uint4)
+template <int P>
 __device__ __forceinline__ uint4 cvt8(const uint4& lo, const uint4& hi, bool do_silu) {
     float f[8];
     const float* a = reinterpret_cast<const float*>(&lo);
@@ -39,9 +90,7 @@ __device__ __forceinline__ uint4 cvt8(const uint4& lo, const uint4& hi, bool do_
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
     }
-    uint4 r;
-    r.x = pack2bf(f[0], f[1]); r.y = pack2bf(f[2], f[3]); r.z = pack2bf(f[4], f[5]); r.w = pack2bf(f[6], f[7]);
-    return r;
+    return pack8<P>(f);
 }
 
 // bias / time-embedding row / activation / scale / residual / (transposed) store of 4 consecutive channels
@@ -67,7 +116,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int gm, int gn, i
         } else {
             uint16_t* o = reinterpret_cast<uint16_t*>(p.VT);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[base + (size_t)j * p.vt_ld] = f2bf(v[j]);
+            for (int j = 0; j < 4; ++j) o[base + (size_t)j * p.vt_ld] = cvt16_rt(v[j], p.c_dt);
         }
     } else {
         store4(p.C, (size_t)gm * p.ldc + gn, p.c_dt, v);

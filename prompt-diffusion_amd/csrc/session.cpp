@@ -667,14 +667,11 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "attn_legacy")) { e->opt_attn_legacy = value != 0; return 0; }
     if (!strcmp(key, "gn_fuse")) { e->opt_gn_fuse = value != 0; return 0; }
     if (!strcmp(key, "two_streams")) { e->opt_two_streams = value != 0; return 0; }
-    if (!strcmp(key, "diag")) { e->opt_diag = (int)value; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }
     if (!strcmp(key, "patch_split")) { e->opt_patch_split = value != 0; return 0; }
     if (!strcmp(key, "patch_split_fill")) { e->opt_patch_split_fill = (int)value; return 0; }
     if (!strcmp(key, "patch_split_tiles")) { e->opt_patch_split_tiles = (int)value; return 0; }
-    if (!strcmp(key, "gemm8")) { e->opt_gemm8 = value != 0; return 0; }
-    if (!strcmp(key, "gemm8_tiles")) { e->opt_gemm8_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_tiles")) { e->opt_dense_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_k")) { e->opt_dense_k = (int)value; return 0; }
     if (!strcmp(key, "big_tile")) { e->opt_bigtile = value != 0; return 0; }
@@ -695,7 +692,6 @@ int64_t pd_get_stat(pd_engine* e, const char* key) {
     if (!strcmp(key, "weight_bytes")) return (int64_t)e->weight_bytes;
     if (!strcmp(key, "launches")) return (int64_t)e->launches;
     if (!strcmp(key, "steps")) return (int64_t)e->ses.S;
-    if (!strcmp(key, "gemm8_launches")) return (int64_t)e->gemm8_launches;
     return -1;
 }
 

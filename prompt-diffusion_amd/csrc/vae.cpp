@@ -105,7 +105,7 @@ int pd_engine::vae_attention(const Act& x, Act& out) {
             p.taps = 1; p.Cin = C; p.Hin = N; p.Win = 1; p.Hout = N; p.Wout = 1; p.stride = 1;
             p.rows_per_sample = N; p.out_scale = (float)(1.0 / std::sqrt((double)C));
             p.vt_begin = INT_MAX; p.Nout = N; p.splitk = 1; p.big_tile = N >= 1024 ? 1 : 0;
-            if (launch_gemm(p, f32, stream)) { pd_set_error("vae attention: score GEMM launch failed"); return 1; }
+            if (launch_gemm(p, P, stream)) { pd_set_error("vae attention: score GEMM launch failed"); return 1; }
             if (launch_softmax_rows(sc, pr, T, N, N, stream)) { pd_set_error("vae attention: softmax launch failed"); return 1; }
             // out = P v : A = P [N, N] (row stride npad when padded), "weights" = V^T [C][npad]
             GemmParams o{};
@@ -116,7 +116,7 @@ int pd_engine::vae_attention(const Act& x, Act& out) {
             o.taps = 1; o.Cin = N; o.Hin = N; o.Win = 1; o.Hout = N; o.Wout = 1; o.stride = 1;
             o.rows_per_sample = N; o.out_scale = 1.f; o.vt_begin = INT_MAX; o.Nout = C; o.splitk = 1;
             o.big_tile = N >= 1024 ? 1 : 0;
-            if (launch_gemm(o, f32, stream)) { pd_set_error("vae attention: value GEMM launch failed"); return 1; }
+            if (launch_gemm(o, P, stream)) { pd_set_error("vae attention: value GEMM launch failed"); return 1; }
             launches += 3;
         }
     }

@@ -15,7 +15,9 @@ import numpy as np
 
 from .weights import ModelConfig, SD15
 
-PD_PREC_BF16, PD_PREC_F32 = 0, 1
+PD_PREC_BF16, PD_PREC_F32, PD_PREC_F16, PD_PREC_F16X2 = 0, 1, 2, 3
+PRECISIONS = {"bf16": PD_PREC_BF16, "f32": PD_PREC_F32, "fp32": PD_PREC_F32, "f16": PD_PREC_F16, "fp16": PD_PREC_F16,
+              "f16x2": PD_PREC_F16X2}
 PD_MEM_HOST, PD_MEM_DEVICE = 0, 1
 PD_DT_F32, PD_DT_F16, PD_DT_BF16 = 0, 1, 2
 PD_GET_LATENTS, PD_GET_PRED_X0, PD_GET_EPS = 0, 1, 2
@@ -145,7 +147,7 @@ EXPORTS = [
 ]
 
 
-def make_config(cfg: ModelConfig, precision: int = PD_PREC_BF16, stream_f32: bool = False) -> pd_config:
+def make_config(cfg: ModelConfig, precision: int = PD_PREC_F16, stream_f32: bool = False) -> pd_config:
     c = pd_config()
     c.in_channels, c.out_channels = cfg.in_channels, cfg.out_channels
     c.hint_channels, c.query_channels = cfg.hint_channels, cfg.query_channels
@@ -199,12 +201,14 @@ class _Buf:
 class Engine:
     """One engine <-> one GPU <-> one HIP stream (SURVEY.md §8b threading row)."""
 
-    def __init__(self, cfg: ModelConfig = SD15, device: int = 0, precision: str = "bf16", stream_f32: bool = False,
+    def __init__(self, cfg: ModelConfig = SD15, device: int = 0, precision: str = "f16", stream_f32: bool = False,
                  lib_path: Optional[str] = None):
+        """precision: "f16" (default: the reference's own GPU dtype, README.md:44-45), "bf16", "f16x2" (split fp16
+        operands over fp32 storage) or "f32"."""
         _torch_runtime_first()
         self.lib = load_library(lib_path)
         self.cfg = cfg
-        self.precision = {"bf16": PD_PREC_BF16, "f32": PD_PREC_F32, "fp32": PD_PREC_F32}[precision]
+        self.precision = PRECISIONS[precision]
         self.device = device
         self._h = C.c_void_p()
         c = make_config(cfg, self.precision, stream_f32)

@@ -13,7 +13,8 @@ absent in this image and only needed by training code at module import (SURVEY.m
 DDIMSampler.register_buffer is overridden because the stock one force-moves buffers to
 "cuda" (cldm/ddim_hacked.py:17-21) and there is no GPU here.
 
-Usage: python tests/golden/make_golden.py [--skip-sd15]
+Usage: python tests/golden/make_golden.py [--skip-sd15] [--only sd15_s50,sd15_512_s50]   (the 50-step cases take
+~3 and ~12 minutes on 8 cores and are generated only when named)
 """
 import argparse
 import json
@@ -183,6 +184,26 @@ def run_net_case(tag, cfg, W, B, h, w, S, cfg_scale, eta, out):
     np.savez_compressed(os.path.join(out, f"net_{tag}.npz"), **res)
     print(f"[golden] net_{tag}: eps |mean| {np.abs(res['eps']).mean():.4f}, "
           f"x_final |mean| {np.abs(res['samples']).mean():.4f}")
+
+
+def run_traj_case(tag, cfg, W, B, h, w, S, cfg_scale, keep, out):
+    """A whole DDIM trajectory of the reference sampler on the headline 50-step schedule: x_inter at the steps in `keep`
+    (index into intermediates['x_inter'], 0 = x_T) plus the final sample.  Inputs come from the seeded recipe."""
+    model, cn, un = build_reference(cfg, W)
+    inp = W.synth_inputs(cfg, B, h, w)
+    tt = {k: torch.from_numpy(v) for k, v in inp.items()}
+    cond = {"c_crossattn": [tt["ctx_cond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    uc = {"c_crossattn": [tt["ctx_uncond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    sampler = make_sampler(model)
+    with torch.no_grad():
+        samples, inter = sampler.sample(S, B, (cfg.in_channels, h, w), cond, eta=0.0, x_T=tt["x_T"],
+                                        unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc,
+                                        log_every_t=1, verbose=False)
+    keep = sorted(set(int(k) for k in keep if 0 <= k <= S))
+    np.savez_compressed(os.path.join(out, f"net_{tag}.npz"), B=B, h=h, w=w, S=S, cfg_scale=cfg_scale, eta=0.0,
+                        keep=np.asarray(keep, np.int64), x_inter=np.stack([t2n(inter["x_inter"][k]) for k in keep]),
+                        samples=t2n(samples))
+    print(f"[golden] net_{tag}: {len(keep)} latents kept, x_final |mean| {np.abs(t2n(samples)).mean():.4f}")
 
 
 def run_mask_case(tag, cfg, W, B, h, w, S, cfg_scale, out):
@@ -406,6 +427,13 @@ def main():
     if want("sd15") and not args.skip_sd15:
         # BASELINE config #1: 256x256 (latent 32x32), 5 DDIM steps, bs=1, CFG
         run_net_case("sd15_b1_32x32_s5", W.SD15, W, B=1, h=32, w=32, S=5, cfg_scale=7.5, eta=0.0, out=out)
+    # the headline 50-step schedule (BASELINE metric: per-step latent error at 50-step DDIM), pinned by the reference itself:
+    # 256x256 with every latent, and one 512x512 image (BASELINE config #2's shape) with a subset of the latents
+    if only is not None and "sd15_s50" in only:
+        run_traj_case("sd15_b1_32x32_s50", W.SD15, W, B=1, h=32, w=32, S=50, cfg_scale=7.5, keep=range(51), out=out)
+    if only is not None and "sd15_512_s50" in only:
+        run_traj_case("sd15_b1_64x64_s50", W.SD15, W, B=1, h=64, w=64, S=50, cfg_scale=7.5,
+                      keep=[0, 1, 2, 3, 4, 5, 10, 20, 30, 40, 49, 50], out=out)
 
 
 if __name__ == "__main__":

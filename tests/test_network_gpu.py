@@ -1,14 +1,17 @@
 """End-to-end parity of the HIP path (through the C ABI) with the golden fixtures generated from the
 reference and with the NumPy oracle.
 
-Tolerances (max |diff| / max |ref| per tensor):
-  fp32 engine mode : 2e-4 per denoising step -- same arithmetic as the reference, different summation
-                     order.  This is the mode that meets the north-star bound (1e-3 per step).
-  bf16 engine mode : eps (one apply_model) within 3e-2; latents within 5e-2 per step on the 5-step
-                     configs.  bf16 MFMA operands carry 2^-9 relative rounding per element; ~100
-                     contraction layers deep that is ~1.1-1.4e-2 rms on eps (measured), and classifier-free
-                     guidance e_u + 7.5 (e_c - e_u) multiplies the uncorrelated part by ~10 at the
-                     5-step schedule's large eps coefficient.  See DESIGN.md "Precision".
+Tolerances (max |diff| / max |ref| per tensor); the north-star bound is 1e-3 per denoising step:
+  fp32 engine mode  : 2e-4 per step on every fixture -- the reference's arithmetic, different summation order.
+  f16x2 engine mode : 1e-3 per step on every fixture (split fp16 operands over fp32 storage; measured ~1e-5).
+  fp16 engine mode  : the benchmarked default (the reference's own GPU dtype).  On the headline 50-step schedule
+                      (fixtures net_sd15_b1_{32x32,64x64}_s50, produced by the reference sampler itself) every single
+                      denoising step is within 1e-3 of the reference's step from the same latent.  On the 5- and 4-step
+                      fixtures one step moves the latent ~8x further (the eps coefficient of the DDIM update), so the
+                      same eps error shows as ~3.8e-3 there: bounds 5e-3 (eps 2.5e-3).
+  bf16 engine mode  : eps within 3e-2; latents within 5e-2 per step on the 5-step configs (2^-9 operand rounding,
+                      ~100 contraction layers deep, CFG 7.5 amplifies the uncorrelated part ~10x).
+See DESIGN.md "Precision" for the error budget (tools/prec_probe.py reproduces it).
 """
 import json
 import os
@@ -38,13 +41,6 @@ def _engine(cfg, prec, **kw):
 @pytest.fixture(scope="module")
 def tiny_f32():
     e = _engine(W.TINY, "f32")
-    yield e
-    e.close()
-
-
-@pytest.fixture(scope="module")
-def tiny_bf16():
-    e = _engine(W.TINY, "bf16")
     yield e
     e.close()
 
@@ -114,19 +110,22 @@ def test_tiny_ddim_trajectory_f32(golden_dir, tiny_f32, tag):
     assert relerr(out, g["samples"]) < 2e-4
 
 
+@pytest.mark.parametrize("prec,tol_eps,tol_step", [("bf16", 3e-2, 5e-2), ("f16", 2.5e-3, 5e-3), ("f16x2", 2e-4, 1e-3)])
 @pytest.mark.parametrize("tag", ["tiny_b2_16x16_s5", "tiny_b1_8x24_s4"])
-def test_tiny_bf16(golden_dir, tiny_bf16, tag):
+def test_tiny_reduced_precision(golden_dir, tag, prec, tol_eps, tol_step):
+    e = _engine(W.TINY, prec)
     g = np.load(os.path.join(golden_dir, f"net_{tag}.npz"))
     inp, x_in, t_in, ctx, pair, qry = _cfg_inputs(W.TINY, g)
-    eps = tiny_bf16.eps(x_in, t_in, ctx, pair, qry)
-    assert relerr(eps, g["eps"]) < 3e-2
+    eps = e.eps(x_in, t_in, ctx, pair, qry)
+    assert relerr(eps, g["eps"]) < tol_eps
     B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
-    out, inter = tiny_bf16.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"],
-                                       pair=inp["pair"], query=inp["query"], steps=S, cfg_scale=float(g["cfg_scale"]),
-                                       return_intermediates=True)
+    out, inter = e.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"],
+                               pair=inp["pair"], query=inp["query"], steps=S, cfg_scale=float(g["cfg_scale"]),
+                               return_intermediates=True)
     errs = [relerr(inter[i], g["x_inter"][i]) for i in range(S + 1)]
-    print("bf16 per-step latent error", errs)
-    assert max(errs) < 5e-2
+    print(prec, "per-step latent error", ["%.2e" % v for v in errs])
+    assert np.isfinite(out).all() and max(errs) < tol_step
+    e.close()
 
 
 def test_fused_groupnorm_option_matches(golden_dir):
@@ -208,7 +207,8 @@ def test_errors_are_reported_not_thrown(tiny_f32):
     e.close()
 
 
-@pytest.mark.parametrize("prec,tol_step,tol_eps", [("f32", 2e-4, 2e-4), ("bf16", 5e-2, 3e-2)])
+@pytest.mark.parametrize("prec,tol_step,tol_eps", [("f32", 2e-4, 2e-4), ("f16x2", 1e-3, 2e-4), ("f16", 5e-3, 2.5e-3),
+                                                   ("bf16", 5e-2, 3e-2)])
 def test_sd15_config1(golden_dir, prec, tol_step, tol_eps):
     """BASELINE config #1: SD1.5 + Prompt-Diffusion ControlNet, 256x256 (latent 32x32), 5 DDIM steps, bs 1,
     against the trajectory the reference itself produced on CPU."""
@@ -229,7 +229,55 @@ def test_sd15_config1(golden_dir, prec, tol_step, tol_eps):
                                query=inp["query"], steps=S, cfg_scale=float(g["cfg_scale"]), return_intermediates=True)
     errs = [relerr(inter[i], g["x_inter"][i]) for i in range(S + 1)]
     print(f"sd15 {prec} per-step latent relerr:", ["%.2e" % v for v in errs])
-    assert max(errs) < tol_step
+    assert np.isfinite(out).all() and max(errs) < tol_step
+    e.close()
+
+
+# one denoising step from the reference's own latent: what "per denoising step" means for the north-star bound
+ONE_STEP_TOL = {"f32": 2e-4, "f16x2": 2e-4, "f16": 1e-3, "bf16": 1e-2}
+TRAJ_TOL = {"f32": 1e-3, "f16x2": 1e-3, "f16": 1.5e-2, "bf16": 1.5e-1}   # accumulated over all 50 steps (chaotic growth included)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x2", "f16", "bf16"])
+@pytest.mark.parametrize("tag", ["sd15_b1_32x32_s50", "sd15_b1_64x64_s50"])
+def test_sd15_headline_schedule_per_step(golden_dir, tag, prec):
+    """The headline schedule (50 DDIM steps, CFG 7.5) against trajectories the reference sampler produced on CPU: 256x256
+    with every latent, 512x512 (BASELINE config #2's shape) with a subset.  For each kept pair of consecutive latents the
+    engine is handed the reference's x_i and must reproduce x_{i+1}: the per-denoising-step error of the north star.  The
+    256x256 case also runs the whole loop from x_T and bounds the accumulated deviation."""
+    path = os.path.join(golden_dir, f"net_{tag}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{tag} fixture not generated")
+    if prec in ("f32", "f16x2") and "64x64" in tag:
+        pytest.skip("covered at 32x32 (fp32-storage modes take minutes per 512x512 trajectory)")
+    g = np.load(path)
+    cfg = W.SD15
+    B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
+    keep = [int(k) for k in g["keep"]]
+    ref = {k: g["x_inter"][j] for j, k in enumerate(keep)}
+    e = _engine(cfg, prec)
+    inp = W.synth_inputs(cfg, B, h, w)
+    kw = dict(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"], query=inp["query"],
+              steps=S, cfg_scale=float(g["cfg_scale"]))
+    n = e.sample_begin(**kw)
+    assert n == S
+    pairs = [k for k in keep if k + 1 in ref]
+    if prec in ("f32", "f16x2"):
+        pairs = pairs[:3] + pairs[-2:]
+    errs = []
+    for i in pairs:
+        e.sample_set_latents(ref[i])
+        e.sample_step(i)
+        errs.append(relerr(e.sample_get(), ref[i + 1]))
+    e.sample_end()
+    print(f"{tag} {prec}: one-step relerr max {max(errs):.2e} (first {errs[0]:.2e}, last {errs[-1]:.2e}) over {len(pairs)} steps")
+    assert max(errs) < ONE_STEP_TOL[prec]
+    if "32x32" in tag:
+        out, inter = e.ddim_sample(return_intermediates=True, **kw)
+        acc = [relerr(inter[k], ref[k]) for k in keep]
+        print(f"{tag} {prec}: accumulated relerr after 10/25/50 steps {acc[10]:.2e} {acc[25]:.2e} {acc[50]:.2e}")
+        assert np.isfinite(out).all() and max(acc) < TRAJ_TOL[prec]
+        assert relerr(out, g["samples"]) < TRAJ_TOL[prec]
     e.close()
 
 
