@@ -10,11 +10,14 @@ random-initialised on the device (no checkpoint exists offline), inputs syntheti
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` without a torchrun environment launches that second line itself, as a CHILD process and
+before anything touches the GPU, and relays the child's JSON line.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,6 +53,64 @@ def cpu_baseline(ddim_steps: int):
                        f"NumPy/OpenBLAS fp32; extrapolated x{ddim_steps}")
 
 
+def parity_leg(E, W, precision, stream_f32, device):
+    """The second half of BASELINE's metric: per-step latent error against the reference's own CPU trajectories
+    (tests/golden/, made by tests/golden/make_golden.py from /root/reference), computed in this run with the seeded
+    synthetic weights those fixtures were made with.  `per_step_relerr`: 50-step schedule (the metric's schedule) --
+    the engine gets the reference's x_i and must reproduce x_{i+1}; max over the sampled steps of max|dx| / max|x_ref|."""
+    import numpy as np
+    gdir = os.path.join(ROOT, "tests", "golden")
+    f50, f5 = os.path.join(gdir, "net_sd15_b1_32x32_s50.npz"), os.path.join(gdir, "net_sd15_b1_32x32_s5.npz")
+    if not os.path.exists(f50):
+        return None
+    cfg = W.SD15
+    e = E.Engine(cfg, device=device, precision=precision, stream_f32=stream_f32)
+    for n, a in W.iter_synth(cfg):
+        e.load_tensor(n, a)
+    g = np.load(f50)
+    B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
+    inp = W.synth_inputs(cfg, B, h, w)
+    kw = dict(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"], query=inp["query"],
+              steps=S, cfg_scale=float(g["cfg_scale"]))
+    ref = g["x_inter"]
+    steps = [0, 1, 2, 3, 4, 9, 19, 29, 39, 49]
+    e.sample_begin(**kw)
+    rel, mabs = [], []
+    for i in steps:
+        e.sample_set_latents(ref[i])
+        e.sample_step(i)
+        d = np.abs(e.sample_get() - ref[i + 1]).max()
+        rel.append(float(d / np.abs(ref[i + 1]).max()))
+        mabs.append(float(d))
+    e.sample_end()
+    out = {"per_step_relerr": max(rel), "per_step_max_abs_err": max(mabs), "steps_checked": steps,
+           "schedule": "50-step DDIM, CFG 7.5, SD1.5 256x256 bs 1 (tests/golden/net_sd15_b1_32x32_s50.npz: the reference's CPU trajectory)",
+           "bound": 1e-3, "mode": precision}
+    if os.path.exists(f5):   # BASELINE config #1: the 5-step trajectory, whole loop from x_T
+        g5 = np.load(f5)
+        o5, inter = e.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"],
+                                  query=inp["query"], steps=int(g5["S"]), cfg_scale=float(g5["cfg_scale"]), return_intermediates=True)
+        out["config1_per_step_relerr"] = max(float(np.abs(inter[i] - g5["x_inter"][i]).max() / np.abs(g5["x_inter"][i]).max())
+                                             for i in range(1, int(g5["S"]) + 1))
+        out["config1"] = "#1: 256x256, 5 DDIM steps, bs 1 (8x larger eps coefficient per step than the 50-step schedule)"
+    e.close()
+    return out
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N-rank job as a child (one process per GPU, RCCL) and relay
+    its output.  Nothing in this process has touched the GPU (no torch import yet), so starting children is safe."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,20 +119,28 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=50)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "f16x2", "f32"],
+                    help="engine mode; f16 (default) is the reference's own GPU dtype (README.md:44-45)")
     ap.add_argument("--stream-f32", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-f32", action="store_true", help="skip the extra fp32-engine-mode measurement")
+    ap.add_argument("--no-f32", "--no-extra-modes", dest="no_f32", action="store_true",
+                    help="skip the extra measurement of the f16x2 mode (fp32-class results) on the same workload")
+    ap.add_argument("--no-parity", action="store_true", help="skip the per-step latent error leg")
     ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=int (experiments)")
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise ControlNet and UNet on one stream in every pass (used for the committed rocprof summary, so\n"
                          "that per-kernel durations are not stretched by the concurrent kernel of the other stream)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pdengine hot path has no CPU fallback")
@@ -89,6 +158,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
     from prompt_diffusion_amd import engine as E
     from prompt_diffusion_amd import weights as W
@@ -144,7 +214,7 @@ def main():
         "metric": "images/sec @ 512x512, 50-step DDIM, bs=8", "value": value, "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic",
+        "dtype": args.precision, "data": "synthetic", "rccl_ranks": world,
         "config": {"workload": f"SD1.5 UNet + Prompt-Diffusion ControlNet, {args.size}x{args.size}, {S}-step DDIM (eta 0), "
                                f"CFG 7.5, bs={B} per GPU (forward batch {2 * B}), random-init weights",
                    "global_batch": world * B, "latent": [h, w], "ddim_steps": S, "parallelism": f"batch-shard x{world}",
@@ -162,7 +232,9 @@ def main():
             eng.set_option("two_streams", 0)
             eng.set_option("profile", 1)
             eng.ddim_sample(**kw)
-            peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+            # f16 MFMA runs at the bf16 rate (MI355X_MICROARCH.md "the F16 forms take the same cycles"); f16x2 issues two
+            # fp16 MFMAs per 4 K-elements where f16 issues one per 8: a quarter of the fp16 rate
+            peak = {"bf16": PEAK_BF16_TFLOPS, "f16": PEAK_BF16_TFLOPS, "f16x2": PEAK_BF16_TFLOPS / 4, "f32": PEAK_F32_TFLOPS}[args.precision]
             classes = {}
             for name, k in (("igemm_kernel[conv3x3]", 0), ("igemm_kernel[linear/conv1x1]", 1), ("conv3x3_patch_kernel", 3),
                             ("attn_kernel", 2)):
@@ -173,9 +245,18 @@ def main():
             import csv, tempfile
             with tempfile.NamedTemporaryFile("r", suffix=".csv") as tf:
                 eng.profile_dump(tf.name)
-                rows = [r for r in csv.DictReader(open(tf.name)) if r["klass"] == "1" and int(r["K"]) <= 1280]
+                allrows = list(csv.DictReader(open(tf.name)))
+            eb = 4 if args.precision in ("f32", "f16x2") else 2
+
+            def alg_bytes(r):   # A rows (a conv3x3 reads its input once, not once per tap) + weights + output, each moved once
+                M, N, K = int(r["M"]), int(r["N"]), int(r["K"])
+                taps = 9 if int(r["taps"]) >= 90 else 1
+                return (M * (K // taps) + N * K + M * N) * eb
+            rows = [r for r in allrows if r["klass"] == "1" and int(r["K"]) <= 1280]
+            ig = [r for r in allrows if r["klass"] in ("0", "1")]
+            alg_per_launch = sum(alg_bytes(r) for r in ig) / max(len(ig), 1)
             if rows:
-                by = sum((int(r["M"]) * int(r["K"]) + int(r["N"]) * int(r["K"]) + int(r["M"]) * int(r["N"])) * 2 for r in rows)
+                by = sum(alg_bytes(r) for r in rows)
                 ms_s = sum(float(r["ms"]) for r in rows)
                 classes["igemm_kernel[linear, K<=1280: HBM view]"] = dict(
                     ms=ms_s, launches=len(rows), avg_us=1e3 * ms_s / len(rows), algorithmic_gb_per_s=by / ms_s / 1e6,
@@ -190,14 +271,21 @@ def main():
             n_g = classes["igemm_kernel[conv3x3]"]["launches"] + classes["igemm_kernel[linear/conv1x1]"]["launches"]
             fl_g = sum(classes[k]["tflops"] * classes[k]["ms"] for k in ("igemm_kernel[conv3x3]", "igemm_kernel[linear/conv1x1]"))
             achieved = fl_g / max(ms_g, 1e-9)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            # HBM traffic per launch: PMC counters cannot be collected from inside this process; tools/final_measure.sh runs
+            # the FETCH_SIZE / WRITE_SIZE passes on this same command line (50-step workload) and commits the summary
+            traffic, traffic_source = None, None
+            tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get("igemm_kernel_hbm_bytes_per_launch")
+                    tj = json.load(f)
+                traffic = tj.get("igemm_kernel_hbm_bytes_per_launch")
+                traffic_source = "profiles/r02_pmc_traffic.json: " + tj.get("source", "")
             result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv / linear, all instantiations)",
                                   "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                                  "traffic": traffic, "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,
+                                  "traffic": traffic, "traffic_source": traffic_source,
+                                  "algorithmic_bytes_per_launch": alg_per_launch,
+                                  "traffic_over_algorithmic": (traffic / alg_per_launch) if traffic else None,
+                                  "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,
                                   "flop_per_launch": 1e9 * fl_g / max(n_g, 1), "device_ms_per_pass": ms_g, "by_kernel": classes}
         # first-stage decode of the 8 latents, outside the metric's timed region: reported for context
         try:
@@ -210,23 +298,25 @@ def main():
             assert torch.isfinite(img).all()
         except Exception as ex:   # noqa: BLE001 - context only
             result["vae_decode_ms"] = f"failed: {ex}"
-        if not args.no_f32 and world == 1 and args.precision == "bf16":
-            # the engine's fp32 mode (v_mfma_f32_16x16x4_f32: the mode that meets the 1e-3 per-step parity bound, 2e-4
-            # measured) on the same workload: 1 warm-up + 1 timed pass
+        if not args.no_parity and world == 1:
             eng.close()
-            e32 = E.Engine(cfg, device=local, precision="f32")
-            e32.init_random_weights(1234)
-            e32.ddim_sample(**kw)
+            result["parity"] = parity_leg(E, W, args.precision, args.stream_f32, local)
+        if not args.no_f32 and world == 1 and args.precision in ("f16", "bf16"):
+            # the f16x2 mode (split fp16 operands over fp32 storage: fp32-class results, ~5e-6 per step against every
+            # reference fixture) on the same workload: 1 warm-up + 1 timed pass.  The fp32-MFMA mode is `--precision f32`.
+            eng.close()
+            e2 = E.Engine(cfg, device=local, precision="f16x2")
+            e2.init_random_weights(1234)
+            e2.ddim_sample(**kw)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            o32 = e32.ddim_sample(**kw)
+            o2 = e2.ddim_sample(**kw)
             torch.cuda.synchronize()
-            d32 = time.perf_counter() - t1
-            assert torch.isfinite(o32).all()
-            result["f32_mode"] = {"value": B / d32, "unit": "images/sec", "ms_per_step": 1e3 * d32, "dtype": "f32",
-                                  "path_tflops": B / d32 * tflop_image, "peak_tflops": PEAK_F32_TFLOPS,
-                                  "frac": B / d32 * tflop_image / PEAK_F32_TFLOPS}
-            e32.close()
+            d2 = time.perf_counter() - t1
+            assert torch.isfinite(o2).all()
+            result["f16x2_mode"] = {"value": B / d2, "unit": "images/sec", "ms_per_step": 1e3 * d2, "dtype": "f16x2",
+                                    "path_tflops": B / d2 * tflop_image}
+            e2.close()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(result))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 1
+#define PD_ABI_VERSION 2
 
 /* arithmetic mode of the engine */
 #define PD_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate / norm statistics / softmax */
@@ -109,8 +109,12 @@ typedef struct pd_sample_args {
     const float* control_scales;      /* [13] or NULL (= all 1.0), cldm/cldm.py:335,379 */
     const float* control_scales_step; /* optional [steps][13]: per-step scales in sampling order
                                          (controlnet_keep gating, pipeline :1196-1202,:1229-1235) */
-    const float* noise;       /* eta > 0: [steps][B, in_ch, h, w] standard normal draws, or NULL */
-    int32_t reserved[8];
+    const float* noise;       /* eta > 0: [steps][B, in_ch, h, w] standard normal draws (required then: ddim_hacked.py:230) */
+    const int64_t* timesteps; /* optional, HOST memory whatever `mem` says: [steps] custom DDIM timesteps in sampling order
+                                 (strictly descending) replacing the uniform grid of make_ddim_timesteps -- the (D) pipeline's
+                                 `timesteps=` argument (pipeline_prompt_diffusion.py:101-142) and diffusers' leading-spaced
+                                 grid for step counts that do not divide 1000 */
+    int32_t reserved[6];
 } pd_sample_args;
 
 const char* pd_last_error(void);
@@ -176,6 +180,11 @@ int pd_make_schedule(pd_engine* e, int32_t steps, float eta, int64_t* timesteps,
 /* instrumentation */
 int pd_synchronize(pd_engine* e);
 void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches on */
+/* PD_MEM_DEVICE inputs: make the engine's (non-blocking) streams wait for the work already enqueued on `producer`, the
+ * hipStream_t that wrote those buffers (NULL = the default stream) -- the engine-side half of what `.to(device)` ordering
+ * gives the reference (everything on torch's current stream).  Call before handing device buffers over; outputs need no
+ * counterpart because every call that fills a caller buffer synchronises the engine stream before it returns. */
+int pd_wait_stream(pd_engine* e, void* producer);
 /* Tuning / instrumentation knobs (defaults are the measured best; tests and tools/ flip them for A/B runs):
  *   "verbose", "profile" (HIP events around every contraction launch, see pd_profile_read),
  *   "two_streams" (ControlNet on a second stream beside the UNet encoder, default 1),
@@ -207,6 +216,9 @@ int pd_bench_conv3x3(pd_engine* e, int32_t Bf, int32_t H, int32_t W, int32_t Cin
  * [B, context_len] int32 -> last_hidden_state [B, context_len, context_dim] fp32.  mem: PD_MEM_HOST / PD_MEM_DEVICE for both
  * buffers.  Needs the cond_stage_model.transformer.text_model.* weights (pd_text_weights_missing() == 0). */
 int pd_text_encode(pd_engine* e, const int32_t* ids, int32_t B, int32_t mem, float* out);
+/* clip_skip k > 0 (pipeline_prompt_diffusion.py:398-413): the hidden state after block text_layers - k, passed through
+ * final_layer_norm (= hidden_states[-(k+1)] of transformers' CLIPTextModel); k = 0 is pd_text_encode */
+int pd_text_encode_ex(pd_engine* e, const int32_t* ids, int32_t B, int32_t mem, int32_t clip_skip, float* out);
 int pd_text_weights_missing(pd_engine* e);
 
 /* Same for one Linear / conv1x1 layer ([M,K] x [N,K]^T, optional residual add) in isolation. */

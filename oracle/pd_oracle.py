@@ -53,7 +53,7 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta):
     return sigmas, alphas, alphas_prev
 
 
-def make_schedule(S, eta=0.0, n_timestep=1000, linear_start=0.00085, linear_end=0.0120):
+def make_schedule(S, eta=0.0, n_timestep=1000, linear_start=0.00085, linear_end=0.0120, timesteps=None):
     """DDIMSampler.make_schedule, cldm/ddim_hacked.py:23-52.
 
     Returns dict with ddim_timesteps (int), and the four per-index scalars exactly as
@@ -61,7 +61,9 @@ def make_schedule(S, eta=0.0, n_timestep=1000, linear_start=0.00085, linear_end=
     slice), ddim_alphas_prev (float64 ndarray -> f32 by torch.full), ddim_sigmas,
     ddim_sqrt_one_minus_alphas (np.sqrt(1 - f32 alphas))."""
     _, ac = register_schedule(n_timestep, linear_start, linear_end)
-    ts = make_ddim_timesteps(S, n_timestep)
+    # timesteps (optional): a custom ascending grid in place of make_ddim_timesteps' uniform one -- the (D) pipeline's
+    # `timesteps=` argument (pipeline_prompt_diffusion.py:101-142); the DDIM parameters derive from it the same way
+    ts = make_ddim_timesteps(S, n_timestep) if timesteps is None else np.asarray(timesteps, dtype=np.int64)
     sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(ac, ts, eta)
     return dict(ddim_timesteps=ts, ddim_alphas=alphas.astype(F32),
                 ddim_alphas_prev=np.asarray(alphas_prev, dtype=np.float64).astype(F32),
@@ -304,7 +306,7 @@ def apply_model(sd, cfg, layouts, x, t, context, example_pair, query, control_sc
 
 # ----------------------------------------------------------------------------- sampler
 def p_sample_ddim(sd, cfg, layouts, sched, x, cond, uncond, index, step, cfg_scale,
-                  control_scales=None, noise=None, temperature=1.0):
+                  control_scales=None, noise=None, temperature=1.0, only_mid_control=False):
     """DDIMSampler.p_sample_ddim, cldm/ddim_hacked.py:181-234 (eps parameterisation).
 
     cond/uncond: dicts with 'c_crossattn' [B,L,D], 'example_pair', 'query'.  CFG batching
@@ -316,12 +318,12 @@ def p_sample_ddim(sd, cfg, layouts, sched, x, cond, uncond, index, step, cfg_sca
         t_in = np.concatenate([t, t])
         c_in = {k: np.concatenate([uncond[k], cond[k]]) for k in cond}
         out = apply_model(sd, cfg, layouts, x_in, t_in, c_in["c_crossattn"], c_in["example_pair"],
-                          c_in["query"], control_scales)
+                          c_in["query"], control_scales, only_mid_control)
         e_u, e_c = out[:B], out[B:]
         e_t = e_u + F32(cfg_scale) * (e_c - e_u)
     else:
         e_t = apply_model(sd, cfg, layouts, x, t, cond["c_crossattn"], cond["example_pair"],
-                          cond["query"], control_scales)
+                          cond["query"], control_scales, only_mid_control)
     a_t = sched["ddim_alphas"][index]
     a_prev = sched["ddim_alphas_prev"][index]
     sigma_t = sched["ddim_sigmas"][index]
@@ -343,12 +345,14 @@ def q_sample(cfg, x_start, t, noise):
 
 
 def ddim_sampling(sd, cfg, layouts, S, x_T, cond, uncond, cfg_scale, eta=0.0, control_scales=None,
-                  noises=None, steps_limit: Optional[int] = None, mask=None, x0=None, q_noise=None):
+                  noises=None, steps_limit: Optional[int] = None, mask=None, x0=None, q_noise=None, timesteps=None,
+                  temperature=1.0, only_mid_control=False):
     """DDIMSampler.sample + ddim_sampling, cldm/ddim_hacked.py:55-178 with log_every_t=1.
     mask/x0: the inpainting blend of :154-157, with the q_sample noise of each step supplied (q_noise[i]).
 
     Returns (samples, x_inter list of S+1 latents, pred_x0 list)."""
-    sched = make_schedule(S, eta, cfg.timesteps, cfg.linear_start, cfg.linear_end)
+    sched = make_schedule(S, eta, cfg.timesteps, cfg.linear_start, cfg.linear_end, timesteps)
+    S = len(sched["ddim_timesteps"])
     img = x_T
     x_inter, preds = [img], [img]
     time_range = np.flip(sched["ddim_timesteps"])
@@ -361,7 +365,7 @@ def ddim_sampling(sd, cfg, layouts, S, x_T, cond, uncond, cfg_scale, eta=0.0, co
             img = (img_orig * mask + (F32(1.0) - mask) * img).astype(F32)
         nz = None if noises is None else noises[i]
         img, pred_x0, _ = p_sample_ddim(sd, cfg, layouts, sched, img, cond, uncond, index, int(step),
-                                        cfg_scale, control_scales, nz)
+                                        cfg_scale, control_scales, nz, temperature, only_mid_control)
         x_inter.append(img)
         preds.append(pred_x0)
     return img, x_inter, preds
@@ -477,14 +481,16 @@ def unipc2_sample(eps_fn, x_T, alphas_cumprod, timesteps):
 # pre-LN blocks with causal self-attention and quick-GELU MLP, final LayerNorm.  The model code lives in the
 # `transformers` dependency (not in the reference tree); this restates its published architecture and is pinned against
 # `transformers.CLIPTextModel` itself run in the build container (tests/golden/make_golden.py, clip_*.npz).
-def clip_text_forward(sd, cfg, ids, prefix="cond_stage_model.transformer.text_model."):
+def clip_text_forward(sd, cfg, ids, prefix="cond_stage_model.transformer.text_model.", clip_skip=0):
+    """clip_skip k: hidden_states[-(k+1)] + final_layer_norm (pipeline_prompt_diffusion.py:398-413) = the first
+    text_layers - k blocks."""
     p = lambda n: sd[prefix + n]
     B, L = ids.shape
     C, H = cfg.context_dim, cfg.text_heads
     dh = C // H
     x = p("embeddings.token_embedding.weight")[ids] + p("embeddings.position_embedding.weight")[None, :L]
     causal = np.triu(np.full((L, L), -np.inf, F32), k=1)
-    for i in range(cfg.text_layers):
+    for i in range(cfg.text_layers - int(clip_skip or 0)):
         pre = f"encoder.layers.{i}."
         h = layer_norm(x, p(pre + "layer_norm1.weight"), p(pre + "layer_norm1.bias"), eps=1e-5)
         q = linear(h, p(pre + "self_attn.q_proj.weight"), p(pre + "self_attn.q_proj.bias")) * F32(dh ** -0.5)

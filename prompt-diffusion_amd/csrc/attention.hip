@@ -21,6 +21,26 @@ namespace {
 
 constexpr int TK = 64;  // keys per tile
 
+// 2-byte V^T tiles: 128-byte rows (64 keys) holding the keys PERMUTED inside each group of 32, so that the 8 keys one lane
+// feeds to a K = 32 PV MFMA (keys 4*fq + j of the two 16-key S^T tiles 2u and 2u+1 -- the order P already has in
+// registers) are 16 contiguous bytes, with the 16-byte chunks XOR-swizzled like the GEMM's operand rows: one conflict-free
+// ds_read_b128 per fragment.  (Round 1 read two 8-byte halves from 144-byte rows; hipcc merged them into a ds_read2_b64,
+// which is banked mod 32: 2-way conflicts, 47 % of the kernel's LDS cycles.)
+//   slot(key) = 32*(key/32) + 8*((key%16)/4) + 4*((key%32)/16) + key%4        (a 2-byte element index inside the row)
+constexpr int VT_ROW = 128;
+__device__ __forceinline__ int vt_slot(int k0) { return (k0 & ~31) + (((k0 & 15) >> 2) << 3) + (((k0 & 31) >> 4) << 2); }
+__device__ __forceinline__ int vt_chunk(int row, int chunk) { return row * VT_ROW + (((chunk ^ (row >> 1)) & 7) << 4); }
+// a staged 16-byte chunk = 8 consecutive keys starting at k0 (multiple of 8) lands as two 8-byte halves
+__device__ __forceinline__ void vt_store(char* tile, int row, int k0, const uint4& v) {
+    const int s0 = vt_slot(k0), s1 = vt_slot(k0 + 4);
+    *reinterpret_cast<uint2*>(tile + vt_chunk(row, s0 >> 3) + (s0 & 7) * 2) = make_uint2(v.x, v.y);
+    *reinterpret_cast<uint2*>(tile + vt_chunk(row, s1 >> 3) + (s1 & 7) * 2) = make_uint2(v.z, v.w);
+}
+// fragment of d-row `row` for the PV step u (keys 32u .. 32u+31), lane quarter fq
+__device__ __forceinline__ uint4 vt_frag(const char* tile, int row, int u, int fq) {
+    return *reinterpret_cast<const uint4*>(tile + vt_chunk(row, 4 * u + fq));
+}
+
 template <int P>
 __device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc) { mma_raw<P>(a, b, acc); }
 
@@ -33,7 +53,7 @@ struct AttnCfg {
     static constexpr int KS = (NCH + 3) / 4;      // k-steps (4 chunks each) of the QK^T product
     static constexpr int NTD = (DH + 15) / 16;    // 16-wide d tiles of the output
     static constexpr int KROW = KS * 64 + 16;     // K tile row stride (odd multiple of 16 B: conflict-free b128 reads)
-    static constexpr int VROW = TK * EB + 16;     // V^T tile row stride
+    static constexpr int VROW = F32 ? TK * EB + 16 : VT_ROW;   // V^T tile row stride (2-byte: swizzled 128-byte rows)
     static constexpr int VCH = TK * EB / 16;      // chunks per V^T row
     static constexpr int SMEM = TK * KROW + NTD * 16 * VROW;
     static_assert((DH * EB) % 16 == 0, "head dim must fill whole 16-byte chunks");
@@ -109,7 +129,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                     }
                 }
             }
-            *reinterpret_cast<uint4*>(sV + d * VROW + c * 16) = v;
+            if constexpr (F32) *reinterpret_cast<uint4*>(sV + d * VROW + c * 16) = v;
+            else vt_store(sV, d, c * 8, v);
         }
         __syncthreads();
 
@@ -187,10 +208,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                 }
 #pragma unroll
                 for (int n = 0; n < NTD; ++n) {
-                    const char* row = sV + (n * 16 + fr) * VROW;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(row + ((2 * u) * 16 + fq * 4) * 2);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(row + ((2 * u + 1) * 16 + fq * 4) * 2);
-                    const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    const uint4 vf = vt_frag(sV, n * 16 + fr, u, fq);
                     mma16<P>(vf, pf[0], o[n][0]);
                     mma16<P>(vf, pf[1], o[n][1]);
                 }
@@ -232,7 +250,7 @@ struct Attn2Cfg {
     // else padded rows
     static constexpr bool KSWZ = KS == 2;
     static constexpr int KROW = KSWZ ? 128 : KS * 64 + 16;
-    static constexpr int VROW = TK * 2 + 16;
+    static constexpr int VROW = VT_ROW;
     static constexpr int K_BYTES = TK * KROW, V_BYTES = NTD * 16 * VROW;
     static constexpr int K_SLOTS = TK * NCH;        // valid 16-byte chunks of a K tile
     static constexpr int V_SLOTS = DH * 8;          // valid chunks of a V^T tile (8 per row of 64 keys)
@@ -267,23 +285,36 @@ template <int P> __device__ __forceinline__ float ref_ceil(float x) {
 }
 template <int P> struct One16 { static constexpr unsigned v = P == DT_F16 ? 0x3C00u : 0x3F80u; };   // 1.0 in the 2-byte type
 
-// P: DT_BF16 or DT_F16
-template <int DH, int P>
-__global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnParams p) {
+// P: DT_BF16 or DT_F16.  Non-causal only (the CLIP text transformer's causal attention runs attn_kernel).
+// The hot loop is written for VALU issue, which bounds this kernel (round-2 counters: 169 vector instructions per wave and
+// 64-key tile, 1028 issue cycles against 448 MFMA cycles): K / V^T tiles come in through raw buffer loads (per-thread
+// 32-bit offsets computed once, the tile advance is a scalar offset; rows past Nk read as zero through the descriptor's
+// range check), LDS addresses are per-thread constants with the double-buffer toggle folded into immediates (the loop is
+// unrolled by two), and everything that only the ragged last tile needs sits behind scalar branches.
+template <int DH, int P, int WPS>
+__global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
     using Cfg = Attn2Cfg<DH>;
-    auto kpos = [](int row, int c) __attribute__((always_inline)) { return Cfg::KSWZ ? (c ^ ((row >> 1) & 7)) : c; };   // chunk slot of K row
-    constexpr int NCH = Cfg::NCH, KS = Cfg::KS, NTD = Cfg::NTD, KROW = Cfg::KROW, VROW = Cfg::VROW;
+    constexpr int NCH = Cfg::NCH, KS = Cfg::KS, NTD = Cfg::NTD, KROW = Cfg::KROW;
+    constexpr int BUF = Cfg::K_BYTES + Cfg::V_BYTES;
+    constexpr int K_IT = Cfg::K_IT, V_IT = Cfg::V_IT;
+    constexpr bool SUBM = Cfg::SUBM, ONES = Cfg::ONES;
+    constexpr int KSM = DH / 32, FQM = (DH % 32) / 8;    // fragment slot of K-dim index DH
+    auto kpos = [](int row, int c) __attribute__((always_inline)) { return Cfg::KSWZ ? (c ^ ((row >> 1) & 7)) : c; };
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int bh = blockIdx.y;
     const int b = bh / p.heads, h = bh - b * p.heads;
     const int q0 = blockIdx.x * 128 + wave * 32;
 
     const char* Qb = reinterpret_cast<const char*>(p.Q) + ((size_t)b * p.q_bs + (size_t)h * DH) * 2;
+    // one descriptor per operand, based at this (sample, head): K rows >= Nk fall outside num_records and load as zero
     const char* Kb = reinterpret_cast<const char*>(p.K) + ((size_t)b * p.k_bs + (size_t)h * DH) * 2;
     const char* Vb = reinterpret_cast<const char*>(p.VT) + ((size_t)b * p.vt_bs + (size_t)h * DH * p.vt_ld) * 2;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Kb), 0, (int)(((size_t)(p.Nk - 1) * p.ldk + DH) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Vb), 0, (int)((size_t)DH * p.vt_ld * 2), 0x00020000);   // whole rows (vt_ld is a multiple of 8): the range check works on dwords
 
     uint4 qf[KS][2];
 #pragma unroll
@@ -297,8 +328,6 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
         }
     }
     const float sl2 = p.scale * 1.4426950408889634f;
-    constexpr bool SUBM = Cfg::SUBM, ONES = Cfg::ONES;
-    constexpr int KSM = DH / 32, FQM = (DH % 32) / 8;    // fragment slot of K-dim index DH
     if constexpr (SUBM) {   // Q <- Q * scale * log2(e): logits leave the MFMA in exp2 units
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -316,8 +345,27 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
     // zero the pad chunks / pad rows of both LDS buffers once (they never change)
     for (int i = tid; i < Cfg::SMEM / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
 
-    // staging registers (named: see gemm.hip) and their per-thread slots
-    uint4 kr0, kr1, kr2, vr0, vr1, vr2;
+    // ---- per-thread staging slots, computed once: buffer offsets (bytes, tile 0) and LDS byte offsets (buffer 0)
+    unsigned k_off[K_IT], v_off[V_IT];
+    int k_lds[K_IT], v_lds0[V_IT], v_lds1[V_IT];
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+        const int s = tid + 256 * i;
+        const int r = s / NCH, c = s - r * NCH;
+        k_off[i] = (unsigned)((r * p.ldk + c * 8) * 2);
+        k_lds[i] = r * KROW + kpos(r, c) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) {
+        const int s = tid + 256 * i;
+        const int d = s >> 3, c = s & 7;
+        v_off[i] = (unsigned)((d * p.vt_ld + c * 8) * 2);
+        const int s0 = vt_slot(c * 8), s1 = vt_slot(c * 8 + 4);
+        v_lds0[i] = Cfg::K_BYTES + vt_chunk(d, s0 >> 3) + (s0 & 7) * 2;
+        v_lds1[i] = Cfg::K_BYTES + vt_chunk(d, s1 >> 3) + (s1 & 7) * 2;
+    }
+    // piece i of a tile exists for the waves with wave*64 + 256*i < SLOTS (slot counts are multiples of 64: wave-uniform)
+    uint4 kr0, kr1, kr2, vr0, vr1, vr2;   // staging registers (named: see gemm.hip)
     auto KR = [&](auto I) __attribute__((always_inline)) -> uint4& {
         constexpr int i = decltype(I)::value;
         if constexpr (i == 0) return kr0; else if constexpr (i == 1) return kr1; else return kr2;
@@ -326,65 +374,46 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
         constexpr int i = decltype(I)::value;
         if constexpr (i == 0) return vr0; else if constexpr (i == 1) return vr1; else return vr2;
     };
-    // per-thread slot geometry, computed once
-    int k_goff[3], v_goff[3];   // element offsets inside the K / V^T buffers (token 0 of the tile)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int s = tid + 256 * i;
-        const int r = s / NCH, c = s - r * NCH;
-        k_goff[i] = r * p.ldk + c * 8;
-        const int d = s >> 3, cv = s & 7;
-        v_goff[i] = d * p.vt_ld + cv * 8;
-    }
     auto load_tile = [&](int t0) __attribute__((always_inline)) {
-        if (t0 + TK <= p.Nk) {   // interior tile: plain loads, no masks
-            static_for<Cfg::K_IT>([&](auto I) __attribute__((always_inline)) {
-                constexpr int i = decltype(I)::value;
-                const bool in = (i + 1) * 256 <= Cfg::K_SLOTS || tid + 256 * i < Cfg::K_SLOTS;
-                KR(I) = *reinterpret_cast<const uint4*>(Kb + (in ? ((size_t)t0 * p.ldk + k_goff[i]) * 2 : 0));
-            });
-            static_for<Cfg::V_IT>([&](auto I) __attribute__((always_inline)) {
-                constexpr int i = decltype(I)::value;
-                const bool in = (i + 1) * 256 <= Cfg::V_SLOTS || tid + 256 * i < Cfg::V_SLOTS;
-                VR(I) = *reinterpret_cast<const uint4*>(Vb + (in ? ((size_t)v_goff[i] + t0) * 2 : 0));
-            });
-            return;
-        }
-        static_for<Cfg::K_IT>([&](auto I) __attribute__((always_inline)) {
-            const int s = tid + 256 * decltype(I)::value;
-            const int r = s / NCH, c = s - r * NCH;
-            const int key = t0 + r;
-            const bool ok = s < Cfg::K_SLOTS && key < p.Nk;
-            const uint4 v = *reinterpret_cast<const uint4*>(Kb + (ok ? (size_t)key * p.ldk * 2 + c * 16 : 0));
-            KR(I) = ok ? v : make_uint4(0, 0, 0, 0);
+        const unsigned sk = (unsigned)t0 * (unsigned)p.ldk * 2u, sv = (unsigned)t0 * 2u;   // scalar tile offsets
+        static_for<K_IT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if ((i + 1) * 256 <= Cfg::K_SLOTS || wave * 64 + 256 * i < Cfg::K_SLOTS)
+                KR(I) = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rk, k_off[i], sk, 0));
         });
-        static_for<Cfg::V_IT>([&](auto I) __attribute__((always_inline)) {
-            const int s = tid + 256 * decltype(I)::value;
-            const int d = s >> 3, c = s & 7;
-            const int key = t0 + c * 8;
-            const bool ok = s < Cfg::V_SLOTS && key < p.Nk;
-            uint4 v = *reinterpret_cast<const uint4*>(Vb + (ok ? ((size_t)d * p.vt_ld + key) * 2 : 0));
-            if (!ok) v = make_uint4(0, 0, 0, 0);
-            if (ok && key + 8 > p.Nk) {  // pad keys inside the chunk: 0 * garbage must stay 0
-                uint16_t* w = reinterpret_cast<uint16_t*>(&v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (key + j >= p.Nk) w[j] = 0;
-            }
-            VR(I) = v;
+        static_for<V_IT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if ((i + 1) * 256 <= Cfg::V_SLOTS || wave * 64 + 256 * i < Cfg::V_SLOTS)
+                VR(I) = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rv, v_off[i], sv, 0));
         });
     };
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
-        char* sK = smem + buf * (Cfg::K_BYTES + Cfg::V_BYTES);
-        char* sV = sK + Cfg::K_BYTES;
-        static_for<Cfg::K_IT>([&](auto I) __attribute__((always_inline)) {
-            const int s = tid + 256 * decltype(I)::value;
-            const int r = s / NCH, c = s - r * NCH;
-            if (s < Cfg::K_SLOTS) *reinterpret_cast<uint4*>(sK + r * KROW + kpos(r, c) * 16) = KR(I);
+    // buf is a compile-time constant at every call site: the LDS offsets fold into the store's immediate
+    auto store_tile = [&](int buf, int t0) __attribute__((always_inline)) {
+        char* base = smem + buf * BUF;
+        if (t0 + TK > p.Nk) {   // ragged tile (the last one): V^T pad keys hold whatever follows the row -- 0 * garbage must stay 0
+            static_for<V_IT>([&](auto I) __attribute__((always_inline)) {
+                const int s = tid + 256 * decltype(I)::value;
+                const int key = t0 + (s & 7) * 8;
+                uint4 v = VR(I);
+                unsigned* w = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w[j] &= (key + 2 * j < p.Nk ? 0x0000ffffu : 0u) | (key + 2 * j + 1 < p.Nk ? 0xffff0000u : 0u);
+                VR(I) = v;
+            });
+        }
+        static_for<K_IT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if ((i + 1) * 256 <= Cfg::K_SLOTS || wave * 64 + 256 * i < Cfg::K_SLOTS)
+                *reinterpret_cast<uint4*>(base + k_lds[i]) = KR(I);
         });
-        static_for<Cfg::V_IT>([&](auto I) __attribute__((always_inline)) {
-            const int s = tid + 256 * decltype(I)::value;
-            const int d = s >> 3, c = s & 7;
-            if (s < Cfg::V_SLOTS) *reinterpret_cast<uint4*>(sV + d * VROW + c * 16) = VR(I);
+        static_for<V_IT>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if ((i + 1) * 256 <= Cfg::V_SLOTS || wave * 64 + 256 * i < Cfg::V_SLOTS) {
+                const uint4 v = VR(I);
+                *reinterpret_cast<uint2*>(base + v_lds0[i]) = make_uint2(v.x, v.y);
+                *reinterpret_cast<uint2*>(base + v_lds1[i]) = make_uint2(v.z, v.w);
+            }
         });
     };
 
@@ -393,42 +422,50 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
     for (int n = 0; n < NTD; ++n) { o[n][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[n][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float mrow[2] = {-INFINITY, -INFINITY};   // running max of the RAW logits (scale > 0)
     float lrow[2] = {0.f, 0.f};
-    float mref[2] = {0.f, 0.f};               // SUBM: reference already subtracted by the MFMA (bf16-representable)
+    float mref[2] = {0.f, 0.f};               // SUBM: reference already subtracted by the MFMA (representable in P)
 
     load_tile(0);
     __syncthreads();   // zero fill done before the first tile lands on top of it
     if constexpr (SUBM) {   // K'[key][DH] = 1.0 in both buffers
         for (int i = tid; i < 2 * TK; i += 256)
-            *reinterpret_cast<unsigned*>(smem + (i / TK) * (Cfg::K_BYTES + Cfg::V_BYTES) + (i % TK) * KROW + kpos(i % TK, NCH) * 16) = One16<P>::v;
+            *reinterpret_cast<unsigned*>(smem + (i / TK) * BUF + (i % TK) * KROW + kpos(i % TK, NCH) * 16) = One16<P>::v;
     }
-    if constexpr (ONES) {   // V^T row DH = 1.0 for all 64 keys, both buffers
+    if constexpr (ONES) {   // V^T row DH = 1.0 for all 64 keys, both buffers (a whole row: the key permutation does not matter)
         for (int i = tid; i < 2 * (TK / 2); i += 256)
-            *reinterpret_cast<unsigned*>(smem + (i / (TK / 2)) * (Cfg::K_BYTES + Cfg::V_BYTES) + Cfg::K_BYTES + DH * VROW + (i % (TK / 2)) * 4) = One16<P>::v * 0x10001u;
+            *reinterpret_cast<unsigned*>(smem + (i / (TK / 2)) * BUF + Cfg::K_BYTES + DH * VT_ROW + (i % (TK / 2)) * 4) = One16<P>::v * 0x10001u;
     }
-    store_tile(0);
+    store_tile(0, 0);
     __syncthreads();
 
+    // fragment read offsets (buffer 0): K rows kt*16+fr / V^T rows n*16+fr differ from these by compile-time immediates
+    int kf_off[KS], vf_off[2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf_off[ks] = fr * KROW + kpos(fr, ks * 4 + fq) * 16;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) vf_off[u] = Cfg::K_BYTES + vt_chunk(fr, 4 * u + fq);
+
     const int ntiles = (p.Nk + TK - 1) / TK;
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](auto BUFC, int t) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUFC)::value;
         const int t0 = t * TK;
-        const int buf = t & 1;
         if (t + 1 < ntiles) load_tile(t0 + TK);
-        const char* sK = smem + buf * (Cfg::K_BYTES + Cfg::V_BYTES);
-        const char* sV = sK + Cfg::K_BYTES;
+        const char* sb = smem + buf * BUF;
 
         f32x4 s[4][2];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(sK + (kt * 16 + fr) * KROW + kpos(fr, ks * 4 + fq) * 16);
+                const uint4 kf = *reinterpret_cast<const uint4*>(sb + kf_off[ks] + kt * 16 * KROW);
+                if (ks == 0) {
+                    s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 mma16<P>(kf, qf[ks][0], s[kt][0]);
                 mma16<P>(kf, qf[ks][1], s[kt][1]);
             }
         }
-        if (t0 + TK > p.Nk || p.causal) {  // ragged last tile: mask the pad keys; causal: the keys after the query
+        if (t0 + TK > p.Nk) {  // ragged last tile: mask the pad keys
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -436,7 +473,7 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
                     const int key = t0 + kt * 16 + fq * 4 + j;
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt)
-                        if (key >= p.Nk || (p.causal && key > q0 + qt * 16 + fr)) s[kt][qt][j] = -INFINITY;
+                        if (key >= p.Nk) s[kt][qt][j] = -INFINITY;
                 }
         }
         if constexpr (SUBM) {
@@ -490,34 +527,34 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
             }
         } else {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float mx = max3f(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
-            mx = max3f(mx, s[0][qt][3], s[1][qt][0]);
-            mx = max3f(mx, s[1][qt][1], s[1][qt][2]);
-            mx = max3f(mx, s[1][qt][3], s[2][qt][0]);
-            mx = max3f(mx, s[2][qt][1], s[2][qt][2]);
-            mx = max3f(mx, s[2][qt][3], s[3][qt][0]);
-            mx = max3f(mx, s[3][qt][1], s[3][qt][2]);
-            mx = max3f(mx, mx, s[3][qt][3]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrow[qt], mx);
-            const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * sl2);
-            mrow[qt] = mnew;
-            const float nm = -mnew * sl2;
-            float ps = 0.f;
+            for (int qt = 0; qt < 2; ++qt) {
+                float mx = max3f(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+                mx = max3f(mx, s[0][qt][3], s[1][qt][0]);
+                mx = max3f(mx, s[1][qt][1], s[1][qt][2]);
+                mx = max3f(mx, s[1][qt][3], s[2][qt][0]);
+                mx = max3f(mx, s[2][qt][1], s[2][qt][2]);
+                mx = max3f(mx, s[2][qt][3], s[3][qt][0]);
+                mx = max3f(mx, s[3][qt][1], s[3][qt][2]);
+                mx = max3f(mx, mx, s[3][qt][3]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mnew = fmaxf(mrow[qt], mx);
+                const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * sl2);
+                mrow[qt] = mnew;
+                const float nm = -mnew * sl2;
+                float ps = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][j], sl2, nm));
-                    s[kt][qt][j] = e;
-                    ps += e;
-                }
-            lrow[qt] = fmaf(lrow[qt], alpha, ps);
+                    for (int j = 0; j < 4; ++j) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][j], sl2, nm));
+                        s[kt][qt][j] = e;
+                        ps += e;
+                    }
+                lrow[qt] = fmaf(lrow[qt], alpha, ps);
 #pragma unroll
-            for (int n = 0; n < NTD; ++n) o[n][qt] *= alpha;
-        }
+                for (int n = 0; n < NTD; ++n) o[n][qt] *= alpha;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -531,16 +568,17 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
             }
 #pragma unroll
             for (int n = 0; n < NTD; ++n) {
-                const char* row = sV + (n * 16 + fr) * VROW;
-                const uint2 lo = *reinterpret_cast<const uint2*>(row + ((2 * u) * 16 + fq * 4) * 2);
-                const uint2 hi = *reinterpret_cast<const uint2*>(row + ((2 * u + 1) * 16 + fq * 4) * 2);
-                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                const uint4 vf = *reinterpret_cast<const uint4*>(sb + vf_off[u] + n * 16 * VT_ROW);
                 mma16<P>(vf, pf[0], o[n][0]);
                 mma16<P>(vf, pf[1], o[n][1]);
             }
         }
-        if (t + 1 < ntiles) store_tile(buf ^ 1);   // buffer buf^1 was last read in tile t-1 (barrier below)
+        if (t + 1 < ntiles) store_tile(buf ^ 1, t0 + TK);   // buffer buf^1 was last read in tile t-1 (barrier below)
         __syncthreads();
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
 #pragma unroll
@@ -568,7 +606,7 @@ __global__ __launch_bounds__(256, (DH <= 40 ? 3 : 2)) void attn2_kernel(AttnPara
 template <int DH, int P>
 int launch_attn2(const AttnParams& p, hipStream_t s) {
     using Cfg = Attn2Cfg<DH>;
-    auto kfn = attn2_kernel<DH, P>;
+    auto kfn = attn2_kernel<DH, P, (DH <= 40 ? 3 : 2)>;
     static unsigned long long attr_done = 0;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), Cfg::SMEM, &attr_done)) return 1;
     dim3 grid((p.Nq + 127) / 128, p.B * p.heads);
@@ -590,7 +628,7 @@ int launch_dh(const AttnParams& p, hipStream_t s) {
 template <int P>
 int launch_prec(const AttnParams& p, hipStream_t s) {
     if constexpr (!prec_f32_storage(P)) {
-        if (!p.legacy) {
+        if (!p.legacy && !p.causal) {
             switch (p.dh) {
                 case 8: return launch_attn2<8, P>(p, s);
                 case 16: return launch_attn2<16, P>(p, s);

@@ -26,7 +26,7 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 void* pd_engine::dmalloc(size_t bytes) {
     void* p = nullptr;
     if (bytes == 0) bytes = 16;
-    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { alloc_failed = true; return nullptr; }
     // the engine stream is non-blocking w.r.t. the null stream: finish the clear before anyone uses p
     hipMemset(p, 0, bytes);
     hipDeviceSynchronize();
@@ -326,12 +326,18 @@ int pd_engine::build() {
         pd_set_error("hipEventCreate failed");
         return 1;
     }
-    for (void* p : owned)
-        if (!p) {
-            pd_set_error("hipMalloc failed while building the engine (%zu bytes so far)", weight_bytes);
-            return 1;
-        }
+    if (alloc_failed) {
+        pd_set_error("hipMalloc failed while building the engine (%zu bytes allocated so far)", weight_bytes);
+        return 1;
+    }
     return 0;
+}
+
+int pd_engine::check_arena() {
+    if (!arena.overflow) return 0;
+    pd_set_error("workspace overflow: %zu bytes needed, %zu available (internal sizing error; nothing was launched past it)",
+                 arena.peak, arena.cap);
+    return 1;
 }
 
 // ------------------------------------------------------------------------------------ weights
@@ -606,7 +612,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         }
         if (splitk > 1) {
             p.slab = arena.alloc((size_t)splitk * p.M * m.N * sizeof(float));
-            if (!arena.dry && arena.top > arena.cap) { splitk = 1; p.slab = nullptr; }  // no room (op hooks outside a session)
+            if (!arena.dry && arena.top > arena.cap) { splitk = 1; p.slab = nullptr; arena.overflow = false; }  // no room (op hooks outside a session): unsplit
         }
         p.splitk = splitk;
         p.tile_cnt = (splitk > 1 && opt_splitk_fused) ? tile_cnt : nullptr;
@@ -633,6 +639,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         arena.release(mk);   // stream-ordered: dead once the finalize pass has run
     }
     if (arena.dry) return 0;
+    PD_TRY(check_arena());
     if (f32 && in.dt != DT_F32) {
         pd_set_error("gemm: fp32 mode needs fp32 activations");
         return 1;
@@ -671,6 +678,7 @@ int pd_engine::gn_stats(const Act& x, int& nchunk) {
     if (nchunk > 64) nchunk = 64;
     while ((size_t)x.B * nchunk * 32 * 2 * sizeof(double) > gn_partial_cap && nchunk > 1) nchunk /= 2;
     if (arena.dry) return 0;
+    PD_TRY(check_arena());
     ++launches;
     if (launch_gn_stats(x.p, x.dt, gn_partial, x.B, HW, x.C, 32, nchunk, stream)) {
         pd_set_error("groupnorm stats launch failed (C=%d)", x.C);
@@ -682,6 +690,7 @@ int pd_engine::gn_stats(const Act& x, int& nchunk) {
 int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu) {
     if (opt_gn_single && gn_fused_bundle(x.dt, x.H * x.W, x.C, 32)) {   // slab fits in LDS: one kernel, one read
         if (arena.dry) return 0;
+        PD_TRY(check_arena());
         ++launches;
         if (launch_gn_fused(x.p, x.dt, y.p, y.dt, g, b, x.B, x.H * x.W, x.C, 32, eps, silu ? 1 : 0, stream)) {
             pd_set_error("groupnorm (single kernel) launch failed (C=%d)", x.C);
@@ -734,6 +743,7 @@ int pd_engine::conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, c
 
 int pd_engine::layernorm(const Act& x, Act& y, const float* g, const float* b) {
     if (arena.dry) return 0;
+    PD_TRY(check_arena());
     ++launches;
     if (launch_layernorm(x.p, x.dt, y.p, y.dt, g, b, (int)x.rows(), x.C, 1e-5f, stream)) {
         pd_set_error("layernorm launch failed (C=%d)", x.C);
@@ -746,6 +756,7 @@ int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const v
                          int Nq, int Nk, int C, int heads, bool causal) {
     if (heads <= 0) heads = cfg.num_heads;
     if (arena.dry) return 0;
+    PD_TRY(check_arena());
     AttnParams p{};
     p.Q = Q; p.K = K; p.VT = VT; p.O = O;
     p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.vt_ld = vt_ld;
@@ -909,6 +920,7 @@ int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_
         const Act* a_add = i == 0 ? &ses.control[nctl] : nullptr;
         const Act* b_add = only_mid ? nullptr : &ses.control[nctl - 1 - (int)i];
         if (!arena.dry) {
+            PD_TRY(check_arena());
             ++launches;
             if (launch_concat_add(h.p, a_add ? a_add->p : nullptr, skip.p, b_add ? b_add->p : nullptr, cat.p, S, h.rows(), h.C,
                                   skip.C, stream)) {

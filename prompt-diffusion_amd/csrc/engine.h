@@ -157,11 +157,13 @@ struct Arena {
     char* base = nullptr;
     size_t cap = 0, top = 0, peak = 0;
     bool dry = false;
+    bool overflow = false;   // an allocation ran past cap: every enqueue refuses to launch until the arena is reset
     void* alloc(size_t bytes) {
         size_t a = (top + 255) & ~(size_t)255;
         top = a + bytes;
         if (top > peak) peak = top;
         if (dry) return reinterpret_cast<void*>((size_t)0x1000 + a);
+        if (top > cap) { overflow = true; return base; }   // never hand out memory beyond the workspace
         return base + a;
     }
     size_t mark() const { return top; }
@@ -176,6 +178,7 @@ struct Session {
     int Bf = 0;
     int S = 0;
     std::vector<int64_t> timesteps;  // ascending (ddim_timesteps)
+    std::vector<int64_t> custom_ts;  // copy of pd_sample_args.timesteps (descending), empty = uniform grid
     std::vector<float> alphas, alphas_prev, sigmas, sqrt_1m;
     std::vector<float> scales_step;  // [S][13]
     // device state
@@ -214,6 +217,8 @@ struct pd_engine {
     int run_steps_graph();
     int reg_group = 0;
     std::vector<void*> owned;  // device allocations (weights)
+    bool alloc_failed = false; // a hipMalloc in dmalloc() failed (reported by build() / the bench hooks)
+    int check_arena();         // non-zero (with the error set) when a workspace allocation overflowed
     size_t weight_bytes = 0;
     Arena arena;
     // second context for the ControlNet pass (own stream / workspace / GroupNorm scratch), see forward_eps
@@ -276,7 +281,7 @@ struct pd_engine {
     void build_vres(const std::string& prefix, ResW& r, int cin, int cout);
     void build_vae();
     void build_text();
-    int text_forward(const int* ids_dev, int B, float* out_dev);
+    int text_forward(const int* ids_dev, int B, float* out_dev, int clip_skip);
     int vae_forward(const float* latents_dev, int B, int h, int w, float* out_dev);
     int vae_attention(const Act& x, Act& out);
 
@@ -315,5 +320,5 @@ struct pd_engine {
     int begin(const pd_sample_args* a, bool want_per_step);
     int step(int i);
     int make_schedule(int steps, float eta, std::vector<int64_t>& ts, std::vector<float>& a, std::vector<float>& ap,
-                      std::vector<float>& sg, std::vector<float>& s1m);
+                      std::vector<float>& sg, std::vector<float>& s1m, const int64_t* custom_desc = nullptr);
 };

@@ -1,5 +1,6 @@
 // pdengine: sampling sessions (DDIM loop state, hoisted loop invariants) and the C ABI.
 // Follows DDIMSampler.{make_schedule, sample, ddim_sampling, p_sample_ddim}, cldm/ddim_hacked.py:23-234.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -12,8 +13,10 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ------------------------------------------------------------------------------------ schedule
 // make_beta_schedule('linear') util.py:21-25 + register_schedule ddpm.py:138-159 (alphas_cumprod kept
 // as float32) + make_ddim_timesteps util.py:46-60 + make_ddim_sampling_parameters util.py:63-74.
+// custom_desc (optional): `steps` timesteps in sampling order (descending), replacing the uniform grid -- the DDIM parameters
+// are derived from the list the same way (a_prev of an entry = alphas_cumprod at the next entry, alphas_cumprod[0] after the last)
 int pd_engine::make_schedule(int steps, float eta, std::vector<int64_t>& ts, std::vector<float>& al, std::vector<float>& ap,
-                             std::vector<float>& sg, std::vector<float>& s1m) {
+                             std::vector<float>& sg, std::vector<float>& s1m, const int64_t* custom_desc) {
     const int T_ = cfg.timesteps;
     if (steps < 1 || steps > T_) {
         pd_set_error("steps must be in [1, %d]", T_);
@@ -30,7 +33,18 @@ int pd_engine::make_schedule(int steps, float eta, std::vector<int64_t>& ts, std
     }
     const int c = T_ / steps;
     ts.clear();
-    for (int t = 0; t < T_; t += c) ts.push_back(t + 1);
+    if (custom_desc) {
+        for (int i = steps - 1; i >= 0; --i) {
+            const int64_t t = custom_desc[i];
+            if (t < 0 || t >= T_ || (!ts.empty() && t <= ts.back())) {
+                pd_set_error("custom timesteps must be strictly descending and inside [0, %d)", T_);
+                return 1;
+            }
+            ts.push_back(t);
+        }
+    } else {
+        for (int t = 0; t < T_; t += c) ts.push_back(t + 1);
+    }
     const int n = (int)ts.size();
     if (ts.back() >= T_) {
         pd_set_error("ddim timestep %lld out of range for %d steps (same IndexError as the reference, util.py:65)",
@@ -98,6 +112,7 @@ int pd_engine::session_setup(const pd_sample_args& a, const int64_t* t_rows, int
     const int IH = a.h * 8, IW = a.w * 8;
     const bool dev = a.mem == PD_MEM_DEVICE;
     arena.top = 0;
+    arena.overflow = false;
     s.x_state = reinterpret_cast<float*>(arena.alloc((size_t)B * HW * 8 * 4));
     s.x_in = reinterpret_cast<float*>(arena.alloc((size_t)Bf * HW * 8 * 4));
     s.pred_x0 = reinterpret_cast<float*>(arena.alloc((size_t)B * HW * C * 4));
@@ -273,6 +288,12 @@ static int check_args(pd_engine* e, const pd_sample_args* a) {
     }
     if (!a->x_T || !a->ctx_cond || !a->pair || !a->query) { pd_set_error("x_T, ctx_cond, pair and query are required"); return 1; }
     if (a->use_cfg && !a->ctx_uncond) { pd_set_error("use_cfg needs ctx_uncond"); return 1; }
+    if (a->eta > 0.f && !a->noise) {
+        // the reference always draws noise when eta > 0 (ddim_hacked.py:230); running the eta > 0 coefficients without
+        // it would deflate the sample variance silently
+        pd_set_error("eta > 0 needs the noise draws (pd_sample_args.noise: [steps][B, in_ch, h, w])");
+        return 1;
+    }
     for (auto& p : e->params)
         if (p.group == 0 && !p.loaded) { pd_set_error("weights not loaded: '%s' (and possibly more)", p.name.c_str()); return 1; }
     return 0;
@@ -284,7 +305,11 @@ int pd_engine::begin(const pd_sample_args* a, bool want_per_step) {
     ses.active = false;
     ses.a = *a;
     ses.Bf = a->use_cfg ? 2 * a->batch : a->batch;
-    PD_TRY(make_schedule(a->steps, a->eta, ses.timesteps, ses.alphas, ses.alphas_prev, ses.sigmas, ses.sqrt_1m));
+    ses.custom_ts.clear();
+    if (a->timesteps) ses.custom_ts.assign(a->timesteps, a->timesteps + a->steps);   // always HOST memory
+    ses.a.timesteps = nullptr;
+    PD_TRY(make_schedule(a->steps, a->eta, ses.timesteps, ses.alphas, ses.alphas_prev, ses.sigmas, ses.sqrt_1m,
+                         ses.custom_ts.empty() ? nullptr : ses.custom_ts.data()));
     ses.S = (int)ses.timesteps.size();
     const int S_ = ses.S;
     const int nc = (int)cnet.enc.size() + 1;
@@ -368,6 +393,7 @@ int pd_engine::run_steps_graph() {
     hash_mix(key, flts, sizeof(flts));
     hash_mix(key, ptrs, sizeof(ptrs));
     hash_mix(key, ses.scales_step.data(), ses.scales_step.size() * sizeof(float));
+    hash_mix(key, ses.timesteps.data(), ses.timesteps.size() * sizeof(int64_t));
     for (auto& g : graphs)
         if (g.key == key) {
             HIP_OK(hipGraphLaunch(g.exec, stream));
@@ -536,23 +562,33 @@ int pd_eps(pd_engine* e, const float* x, const int64_t* t, const float* ctx, con
     Act eps;
     PD_TRY(e->forward_eps(0, 1, scales, eps));
     // outputs back to NCHW fp32
+    // one NCHW fp32 staging buffer, reused for every tensor read back (copy_out synchronises before the next use);
+    // it is not part of the workspace dry run, so it is a plain allocation of its own
     const int C = e->cfg.out_channels, HW = h * w;
-    float* tmp = reinterpret_cast<float*>(e->arena.alloc((size_t)Bf * C * HW * 4));
-    if (launch_nhwc_to_nchw(eps.p, eps.dt, tmp, Bf, C, h, w, eps.C, 1.f, e->stream)) return 1;
-    PD_TRY(copy_out(e, tmp, eps_out, (size_t)Bf * C * HW, mem));
-    if (residuals_out) {
+    size_t nmax = (size_t)Bf * C * HW;
+    if (residuals_out)
+        for (size_t i = 0; i <= e->cnet.enc.size(); ++i) nmax = std::max(nmax, (size_t)s.control[i].rows() * s.control[i].C);
+    float* tmp = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&tmp), nmax * 4));
+    auto to_nchw = [&](const void* src, int dt, int b_, int c_, int h_, int w_, int cpad) -> int {
+        if (launch_nhwc_to_nchw(src, dt, tmp, b_, c_, h_, w_, cpad, 1.f, e->stream)) { pd_set_error("pd_eps: layout conversion launch failed"); return 1; }
+        return 0;
+    };
+    int rc = to_nchw(eps.p, eps.dt, Bf, C, h, w, eps.C);
+    if (!rc) rc = copy_out(e, tmp, eps_out, (size_t)Bf * C * HW, mem);
+    if (!rc && residuals_out) {
         size_t off = 0;
-        for (size_t i = 0; i <= e->cnet.enc.size(); ++i) {
+        for (size_t i = 0; i <= e->cnet.enc.size() && !rc; ++i) {
             const Act& c = s.control[i];
             const size_t n = (size_t)c.rows() * c.C;
-            float* t2 = reinterpret_cast<float*>(e->arena.alloc(n * 4));
-            if (launch_nhwc_to_nchw(c.p, c.dt, t2, c.B, c.C, c.H, c.W, c.C, 1.f, e->stream)) return 1;
-            PD_TRY(copy_out(e, t2, residuals_out + off, n, mem));
+            rc = to_nchw(c.p, c.dt, c.B, c.C, c.H, c.W, c.C);
+            if (!rc) rc = copy_out(e, tmp, residuals_out + off, n, mem);
             off += n;
         }
     }
+    (void)hipFree(tmp);
     e->arena.release(mk);
-    return 0;
+    return rc;
 }
 
 int pd_sample_begin(pd_engine* e, const pd_sample_args* args) {
@@ -573,6 +609,7 @@ int pd_sample_get(pd_engine* e, int32_t what, int32_t mem, float* out) {
     const size_t n = (size_t)B * C * h * w;
     const size_t mk = e->arena.mark();
     float* tmp = reinterpret_cast<float*>(e->arena.alloc(n * 4));
+    PD_TRY(e->check_arena());
     const float* src = what == PD_GET_LATENTS ? s.x_state : what == PD_GET_PRED_X0 ? s.pred_x0 : s.eps_g;
     const int cpad = what == PD_GET_LATENTS ? 8 : C;
     if (launch_nhwc_to_nchw(src, DT_F32, tmp, B, C, h, w, cpad, 1.f, e->stream)) return 1;
@@ -591,6 +628,7 @@ int pd_sample_set_latents(pd_engine* e, int32_t mem, const float* latents) {
     const float* src = latents;
     if (mem != PD_MEM_DEVICE) {
         float* tmp = reinterpret_cast<float*>(e->arena.alloc(n * 4));
+        PD_TRY(e->check_arena());
         HIP_OK(hipMemcpyAsync(tmp, latents, n * 4, hipMemcpyHostToDevice, e->stream));
         HIP_OK(hipStreamSynchronize(e->stream));
         src = tmp;
@@ -653,6 +691,22 @@ int pd_synchronize(pd_engine* e) {
 }
 
 void* pd_stream(pd_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+// Orders the engine's streams after the work already enqueued on `producer` (the stream that wrote the PD_MEM_DEVICE
+// buffers about to be handed over; NULL = the legacy default stream).  The engine's streams are non-blocking, so without
+// this nothing orders their reads after the producer's kernels.
+int pd_wait_stream(pd_engine* e, void* producer) {
+    if (!e) { pd_set_error("null engine"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    hipEvent_t ev = nullptr;
+    HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(ev, reinterpret_cast<hipStream_t>(producer));
+    if (r == hipSuccess) r = hipStreamWaitEvent(e->stream, ev, 0);
+    if (r == hipSuccess && e->stream2) r = hipStreamWaitEvent(e->stream2, ev, 0);
+    (void)hipEventDestroy(ev);   // destruction is deferred until the recorded work has completed
+    if (r != hipSuccess) { pd_set_error("pd_wait_stream: %s", hipGetErrorString(r)); return 1; }
+    return 0;
+}
 
 int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!e || !key) { pd_set_error("null argument"); return 1; }

@@ -54,7 +54,7 @@ void pd_engine::build_text() {
 }
 
 // tokens [B, L] int32 (device) -> last_hidden_state [B, L, C] fp32 (device)
-int pd_engine::text_forward(const int* ids_dev, int B, float* out_dev) {
+int pd_engine::text_forward(const int* ids_dev, int B, float* out_dev, int clip_skip) {
     TextW& t = text;
     const int C = cfg.context_dim, F = cfg.text_ff, L = cfg.context_len, H = cfg.text_heads;
     const size_t eb = dt_size(T);
@@ -67,7 +67,9 @@ int pd_engine::text_forward(const int* ids_dev, int B, float* out_dev) {
         }
     }
     const int lpad = round_up(L, 8);
-    for (TextLayerW& l : t.layers) {
+    const int n_run = (int)t.layers.size() - clip_skip;   // hidden_states[-(clip_skip+1)]: output of block n - clip_skip
+    for (int li = 0; li < n_run; ++li) {
+        TextLayerW& l = t.layers[li];
         const size_t mk = arena.mark();
         Act ln = new_act(B, L, 1, C, T);
         PD_TRY(layernorm(x, ln, l.ln1_g, l.ln1_b));
@@ -102,8 +104,12 @@ extern "C" int pd_text_weights_missing(pd_engine* e) {
     return n;
 }
 
-extern "C" int pd_text_encode(pd_engine* e, const int32_t* ids, int32_t B, int32_t mem, float* out) {
+extern "C" int pd_text_encode_ex(pd_engine* e, const int32_t* ids, int32_t B, int32_t mem, int32_t clip_skip, float* out) {
     if (!e || !ids || !out || B < 1) { pd_set_error("bad argument"); return 1; }
+    if (clip_skip < 0 || (e->text.built && clip_skip >= (int)e->text.layers.size())) {
+        pd_set_error("clip_skip %d out of range [0, %d)", clip_skip, e->cfg.text_layers);
+        return 1;
+    }
     if (!e->text.built) { pd_set_error("this engine was created without a text transformer (text_layers = 0)"); return 1; }
     if (e->ses.active) { pd_set_error("pd_text_encode: end the sampling session first"); return 1; }
     for (auto& p : e->params)
@@ -115,7 +121,7 @@ extern "C" int pd_text_encode(pd_engine* e, const int32_t* ids, int32_t B, int32
     std::swap(e->arena, e->arena2);
     Arena saved = e->arena;
     e->arena.base = nullptr; e->arena.cap = 0; e->arena.top = 0; e->arena.peak = 0; e->arena.dry = true;
-    int r = e->text_forward(nullptr, B, nullptr);
+    int r = e->text_forward(nullptr, B, nullptr, 0);
     const size_t need = e->arena.peak + n_in * sizeof(int) + n_out * sizeof(float) + (64u << 20);
     e->arena = saved;
     e->arena.dry = false;
@@ -135,7 +141,7 @@ extern "C" int pd_text_encode(pd_engine* e, const int32_t* ids, int32_t B, int32
         float* dout = reinterpret_cast<float*>(e->arena.alloc(n_out * sizeof(float)));
         if (hipMemcpyAsync(din, ids, n_in * sizeof(int), mem == PD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            e->stream) != hipSuccess) { pd_set_error("token upload failed"); r = 1; }
-        if (!r) r = e->text_forward(din, B, dout);
+        if (!r) r = e->text_forward(din, B, dout, clip_skip);
         if (!r) {
             if (hipMemcpyAsync(out, dout, n_out * sizeof(float), mem == PD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                                e->stream) != hipSuccess ||
@@ -145,4 +151,8 @@ extern "C" int pd_text_encode(pd_engine* e, const int32_t* ids, int32_t B, int32
     }
     std::swap(e->arena, e->arena2);
     return r;
+}
+
+extern "C" int pd_text_encode(pd_engine* e, const int32_t* ids, int32_t B, int32_t mem, float* out) {
+    return pd_text_encode_ex(e, ids, B, mem, 0, out);
 }

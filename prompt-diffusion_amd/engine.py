@@ -56,7 +56,7 @@ class pd_sample_args(C.Structure):
         ("x_T", C.c_void_p), ("ctx_cond", C.c_void_p), ("ctx_uncond", C.c_void_p), ("pair", C.c_void_p),
         ("query", C.c_void_p), ("pair_uncond", C.c_void_p), ("query_uncond", C.c_void_p),
         ("control_scales", C.c_void_p), ("control_scales_step", C.c_void_p), ("noise", C.c_void_p),
-        ("reserved", C.c_int32 * 8),
+        ("timesteps", C.c_void_p), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -105,6 +105,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.pd_text_weights_missing.argtypes = [C.c_void_p]
     lib.pd_text_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.pd_text_encode_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.pd_eps.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]
     lib.pd_control_shape.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 3
     lib.pd_ddim_sample.argtypes = [C.c_void_p, C.POINTER(pd_sample_args), C.c_int32, C.c_void_p, C.c_void_p]
@@ -118,6 +119,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_synchronize.argtypes = [C.c_void_p]
     lib.pd_stream.argtypes = [C.c_void_p]
     lib.pd_stream.restype = C.c_void_p
+    lib.pd_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.pd_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.pd_get_stat.argtypes = [C.c_void_p, C.c_char_p]
     lib.pd_get_stat.restype = C.c_int64
@@ -141,7 +143,7 @@ EXPORTS = [
     "pd_last_error", "pd_abi_version", "pd_engine_create", "pd_engine_destroy", "pd_param_count", "pd_param_info",
     "pd_load_weights", "pd_init_random_weights", "pd_weights_missing", "pd_vae_weights_missing", "pd_vae_decode", "pd_eps", "pd_control_shape", "pd_ddim_sample",
     "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_eps_at", "pd_sample_end",
-    "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_weights_missing",
+    "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_wait_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_encode_ex", "pd_text_weights_missing",
     "pd_profile_read", "pd_profile_dump",
     "pd_op_conv2d", "pd_op_linear", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention",
 ]
@@ -178,6 +180,10 @@ def make_config(cfg: ModelConfig, precision: int = PD_PREC_F16, stream_f32: bool
 
 def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
+
+
+def _to_host(x):
+    return x.detach().cpu().numpy() if _is_torch(x) else np.asarray(x)
 
 
 class _Buf:
@@ -219,6 +225,16 @@ class Engine:
     def _check(self, rc: int):
         if rc != 0:
             raise PdError(self.lib.pd_last_error().decode(errors="replace"))
+
+    def _order_after_torch(self, mem: int, device=None) -> None:
+        """CUDA tensors were produced on torch's current stream; the engine reads them on its own non-blocking streams.
+        Make those wait for everything enqueued on the producer stream so far (incl. the .to()/.contiguous() copies _Buf
+        just launched)."""
+        if mem != PD_MEM_DEVICE:
+            return
+        import torch
+        st = torch.cuda.current_stream(device)
+        self._check(self.lib.pd_wait_stream(self._h, C.c_void_p(st.cuda_stream)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -283,29 +299,32 @@ class Engine:
         else:
             out = np.empty((B, self.cfg.vae_out_ch, 8 * h, 8 * w), np.float32)
             op = out.ctypes.data
+        self._order_after_torch(b.mem)
         self._check(self.lib.pd_vae_decode(self._h, b.ptr, B, h, w, b.mem, op))
         return out
 
     def text_weights_missing(self) -> int:
         return int(self.lib.pd_text_weights_missing(self._h))
 
-    def text_encode(self, input_ids):
+    def text_encode(self, input_ids, clip_skip: int = 0):
         """FrozenCLIPEmbedder.forward after tokenisation (ldm/modules/encoders/modules.py:118-128): token ids
         [B, context_len] -> last_hidden_state [B, context_len, context_dim] fp32 (NumPy in, NumPy out; CUDA int32 tensor in,
-        CUDA tensor out)."""
+        CUDA tensor out).  clip_skip k: hidden_states[-(k+1)] through final_layer_norm (pipeline_prompt_diffusion.py:398-413)."""
+        clip_skip = int(clip_skip or 0)
         if _is_torch(input_ids):
             import torch
             ids = input_ids.to(torch.int32).contiguous()
             if ids.is_cuda:
                 out = torch.empty(tuple(ids.shape) + (self.cfg.context_dim,), dtype=torch.float32, device=ids.device)
-                self._check(self.lib.pd_text_encode(self._h, ids.data_ptr(), ids.shape[0], PD_MEM_DEVICE, out.data_ptr()))
+                self._order_after_torch(PD_MEM_DEVICE)
+                self._check(self.lib.pd_text_encode_ex(self._h, ids.data_ptr(), ids.shape[0], PD_MEM_DEVICE, clip_skip, out.data_ptr()))
                 return out
             input_ids = ids.numpy()
         ids = np.ascontiguousarray(input_ids, np.int32)
         if ids.ndim != 2 or ids.shape[1] != self.cfg.context_len:
             raise ValueError(f"input_ids must be [B, {self.cfg.context_len}]")
         out = np.empty(ids.shape + (self.cfg.context_dim,), np.float32)
-        self._check(self.lib.pd_text_encode(self._h, ids.ctypes.data, ids.shape[0], PD_MEM_HOST, out.ctypes.data))
+        self._check(self.lib.pd_text_encode_ex(self._h, ids.ctypes.data, ids.shape[0], PD_MEM_HOST, clip_skip, out.ctypes.data))
         return out
 
     # ------------------------------------------------------------------ operator boundary
@@ -342,6 +361,7 @@ class Engine:
             eps = np.empty((Bf, self.cfg.out_channels, h, w), np.float32)
             res = np.empty(sum(Bf * c * a * b for c, a, b in shapes), np.float32) if return_control else None
             ep, rp = eps.ctypes.data, (res.ctypes.data if res is not None else None)
+        self._order_after_torch(mem)
         self._check(self.lib.pd_eps(self._h, xb.ptr, tb.ptr, cb.ptr, pb.ptr, qb.ptr,
                                     None if sc is None else sc.ctypes.data, Bf, h, w, mem, ep, rp))
         if not return_control:
@@ -369,7 +389,7 @@ class Engine:
 
     def _args(self, *, x_T, ctx_cond, ctx_uncond, pair, query, steps, cfg_scale, eta=0.0, use_cfg=True,
               guess_mode=False, only_mid_control=False, temperature=1.0, control_scales=None,
-              control_scales_step=None, noise=None, pair_uncond=None, query_uncond=None):
+              control_scales_step=None, noise=None, pair_uncond=None, query_uncond=None, timesteps=None):
         bufs = dict(x_T=_Buf(x_T), ctx_cond=_Buf(ctx_cond), ctx_uncond=_Buf(ctx_uncond), pair=_Buf(pair),
                     query=_Buf(query), pair_uncond=_Buf(pair_uncond), query_uncond=_Buf(query_uncond), noise=_Buf(noise))
         mems = {b.mem for b in bufs.values() if b.mem is not None}
@@ -384,6 +404,12 @@ class Engine:
         for k, b in bufs.items():
             setattr(a, k, b.ptr)
         keep = list(bufs.values())
+        n_steps = self.num_ddim_steps(steps)
+        if timesteps is not None:       # custom grid, sampling order (descending); a.steps = its length
+            ts = np.ascontiguousarray(_to_host(timesteps), dtype=np.int64).reshape(-1)
+            a.steps = n_steps = len(ts)
+            a.timesteps = ts.ctypes.data
+            keep.append(ts)
         if control_scales is not None:
             cs = np.zeros(PD_NUM_CONTROL, np.float32)
             cs[:len(control_scales)] = control_scales
@@ -391,16 +417,17 @@ class Engine:
             keep.append(cs)
         if control_scales_step is not None:
             css = np.ascontiguousarray(control_scales_step, dtype=np.float32)
-            assert css.shape == (self.num_ddim_steps(steps), PD_NUM_CONTROL)
+            assert css.shape == (n_steps, PD_NUM_CONTROL)
             a.control_scales_step = css.ctypes.data
             keep.append(css)
+        self._order_after_torch(a.mem)
         return a, keep, (B, h, w)
 
     def ddim_sample(self, *, return_intermediates: bool = False, **kw):
         """The fused loop (DDIMSampler.sample, cldm/ddim_hacked.py:55-178): returns latents [B,4,h,w]
         (NumPy, or a CUDA tensor when the inputs were CUDA tensors) and optionally x_inter [S+1,B,4,h,w]."""
         a, keep, (B, h, w) = self._args(**kw)
-        S = self.num_ddim_steps(a.steps)
+        S = a.steps if a.timesteps else self.num_ddim_steps(a.steps)
         Cc = self.cfg.in_channels
         if a.mem == PD_MEM_DEVICE:
             import torch
@@ -419,8 +446,9 @@ class Engine:
     def sample_begin(self, **kw) -> int:
         a, keep, shape = self._args(**kw)
         self._check(self.lib.pd_sample_begin(self._h, C.byref(a)))
+        self._keep = keep   # the staged copies stay alive until sample_end()
         self._ses = (shape, a.mem, keep[0].owner if a.mem == PD_MEM_DEVICE else None)
-        return self.num_ddim_steps(a.steps)
+        return a.steps if a.timesteps else self.num_ddim_steps(a.steps)
 
     def sample_step(self, i: int) -> None:
         self._check(self.lib.pd_sample_step(self._h, i))
@@ -438,6 +466,7 @@ class Engine:
 
     def sample_set_latents(self, latents) -> None:
         b = _Buf(latents)
+        self._order_after_torch(b.mem)
         self._check(self.lib.pd_sample_set_latents(self._h, b.mem, b.ptr))
 
     def sample_eps_at(self, t: int, scales: Optional[Sequence[float]] = None):
@@ -450,6 +479,7 @@ class Engine:
 
     def sample_end(self) -> None:
         self._check(self.lib.pd_sample_end(self._h))
+        self._keep = []
 
     # ------------------------------------------------------------------ instrumentation
     def synchronize(self):

@@ -197,11 +197,22 @@ class PromptDiffusionPipeline:
             raise ValueError(f"tokenizer must return ids of shape [{len(prompts)}, {L}], got {ids.shape}")
         return ids
 
-    def _engine_text_encoder(self, prompts: List[str]):
+    def _engine_text_encoder(self, prompts: List[str], clip_skip: Optional[int] = None):
         if self.engine.text_weights_missing() != 0:
             raise ValueError("a string `prompt` needs the cond_stage_model.transformer.text_model.* weights in the engine "
                              "(or a text_encoder callable, or `prompt_embeds`)")
-        return self.engine.text_encode(self._tokenize(prompts))
+        return self.engine.text_encode(self._tokenize(prompts), clip_skip=clip_skip or 0)
+
+    def _encode_text(self, prompts: List[str], clip_skip: Optional[int]):
+        """text_encoder(ids)[0], or with clip_skip the hidden state of layer -(clip_skip+1) through final_layer_norm
+        (pipeline :398-413).  The conditional prompt honours clip_skip; the reference encodes the negative prompt without
+        it (pipeline :455-459)."""
+        if not clip_skip:
+            return _to_numpy(self.text_encoder(prompts))
+        if "clip_skip" not in set(inspect.signature(self.text_encoder).parameters.keys()):
+            raise ValueError("clip_skip needs a text_encoder that accepts `clip_skip=` (the engine's own does); "
+                             "or pass prompt_embeds computed with it")
+        return _to_numpy(self.text_encoder(prompts, clip_skip=clip_skip))
 
     def encode_prompt(self, prompt, num_images_per_prompt, do_cfg, negative_prompt=None, prompt_embeds=None,
                       negative_prompt_embeds=None):
@@ -211,7 +222,7 @@ class PromptDiffusionPipeline:
                 raise ValueError("a string `prompt` needs a text_encoder; this engine consumes the CLIP embedding as a fixed "
                                  "context tensor -- pass `prompt_embeds` (and `negative_prompt_embeds`)")
             plist = [prompt] if isinstance(prompt, str) else list(prompt)
-            prompt_embeds = _to_numpy(self.text_encoder(plist))
+            prompt_embeds = self._encode_text(plist, getattr(self, "_clip_skip", None))
         pe = np.repeat(_to_numpy(prompt_embeds).astype(np.float32), num_images_per_prompt, axis=0)
         ne = None
         if do_cfg:
@@ -250,11 +261,7 @@ class PromptDiffusionPipeline:
             raise NotImplementedError("ip_adapter_image is outside the hot path this engine replaces")
         if cross_attention_kwargs:
             raise NotImplementedError("cross_attention_kwargs (LoRA scale) is outside the hot path this engine replaces")
-        if clip_skip is not None:
-            raise NotImplementedError("clip_skip is not supported: pd_text_encode returns the last layer's output "
-                                      "(FrozenCLIPEmbedder layer=\"last\"); pass prompt_embeds computed with clip_skip instead")
-        if timesteps is not None:
-            raise NotImplementedError("custom `timesteps` are not supported by the fused DDIM loop")
+        self._clip_skip = clip_skip
         # 0/1. defaults + checks (pipeline :1033-1062)
         if not isinstance(control_guidance_start, list) and isinstance(control_guidance_end, list):
             control_guidance_start = len(control_guidance_end) * [control_guidance_start]
@@ -285,11 +292,27 @@ class PromptDiffusionPipeline:
         # 6. latents
         x_T = self.prepare_latents(B, self.engine.cfg.in_channels, height, width, generator, latents)
         # 7.2 controlnet_keep gating and per-step scales (pipeline :1196-1202, :1229-1235; controlnet :371-378)
-        if self.scheduler is not None:      # plug-in scheduler: its own time grid (pipeline :1164-1165)
-            self.scheduler.set_timesteps(num_inference_steps)
+        custom_ts = None
+        if self.scheduler is not None:      # plug-in scheduler: its own time grid (retrieve_timesteps, pipeline :101-142, :1164)
+            if timesteps is not None:
+                if "timesteps" not in set(inspect.signature(self.scheduler.set_timesteps).parameters.keys()):
+                    raise ValueError(f"The current scheduler class {self.scheduler.__class__}'s `set_timesteps` does not support custom"
+                                     f" timestep schedules. Please check whether you are using the correct scheduler.")
+                self.scheduler.set_timesteps(timesteps=timesteps)
+            else:
+                self.scheduler.set_timesteps(num_inference_steps)
             n_steps = len(self.scheduler.timesteps)
         else:
-            n_steps = self.engine.num_ddim_steps(num_inference_steps)
+            # the engine's own DDIM loop with diffusers' DDIMScheduler grid for SD1.5 (timestep_spacing "leading",
+            # steps_offset 1): exactly num_inference_steps entries arange(S) * (T // S) + 1.  For S dividing T this IS the
+            # LDM grid of make_ddim_timesteps and the fused default runs; otherwise -- and for a caller-supplied list -- the
+            # grid goes to the engine as custom timesteps.
+            T = self.engine.cfg.timesteps
+            if timesteps is not None:
+                custom_ts = [int(t) for t in _to_numpy(timesteps).reshape(-1)]
+            elif T % num_inference_steps != 0:
+                custom_ts = [int(t) for t in (np.arange(num_inference_steps) * (T // num_inference_steps))[::-1] + 1]
+            n_steps = len(custom_ts) if custom_ts is not None else self.engine.num_ddim_steps(num_inference_steps)
         keep = [1.0 - float(i / n_steps < control_guidance_start[0] or (i + 1) / n_steps > control_guidance_end[0])
                 for i in range(n_steps)]
         n_ctl = E.PD_NUM_CONTROL
@@ -302,6 +325,8 @@ class PromptDiffusionPipeline:
         kw = dict(x_T=x_T, ctx_cond=pe, ctx_uncond=ne, pair=pair, query=query, steps=num_inference_steps,
                   cfg_scale=float(guidance_scale), eta=float(eta), use_cfg=do_cfg, guess_mode=guess_mode,
                   control_scales_step=scales_step, noise=noise)
+        if custom_ts is not None:
+            kw["timesteps"] = custom_ts
         eng = self.engine
         if self.scheduler is None and callback_on_step_end is None and callback is None:
             lat = eng.ddim_sample(**kw)                                  # 8. the fused loop
@@ -345,6 +370,8 @@ class PromptDiffusionPipeline:
                 extra["eta"] = eta
             if "generator" in params:
                 extra["generator"] = generator
+        elif kw.get("timesteps") is not None:
+            ts = list(kw["timesteps"])
         else:
             ts = [int(t) for t in np.flip(eng.make_schedule(kw["steps"], kw["eta"])["ddim_timesteps"])]
         lat = None

@@ -260,9 +260,18 @@ def run_clip_case(tag, cfg, W, B, out):
     m.load_state_dict(mapped, strict=False)
     ids = W.synth_token_ids(cfg, B)
     with torch.no_grad():
-        z = m(input_ids=torch.from_numpy(ids).long()).last_hidden_state
+        o = m(input_ids=torch.from_numpy(ids).long(), output_hidden_states=True)
+        z = o.last_hidden_state
+        # clip_skip = 2 exactly as the (D) pipeline derives it (pipeline_prompt_diffusion.py:403-413)
+        fln = [mod for name, mod in m.named_modules() if name.endswith("final_layer_norm")][0]
+        z_skip2 = fln(o.hidden_states[-(2 + 1)])
     z = t2n(z)
+    z_skip2 = t2n(z_skip2)
     res = dict(B=B, ids=ids)
+    if z.size <= 200000:
+        res["z_skip2"] = z_skip2
+    else:
+        res["z_skip2_sub"], _ = subsample(z_skip2, 16384)
     if z.size <= 200000:
         res["z"] = z
     else:

@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ but not exported"
     assert sorted(set(E.EXPORTS)) == sorted(set(names))
-    assert lib.pd_abi_version() == 1
+    assert lib.pd_abi_version() == 2
 
 
 def test_struct_layout_matches_header(lib):

@@ -198,6 +198,9 @@ def test_errors_are_reported_not_thrown(tiny_f32):
     with pytest.raises(E.PdError, match="out of range"):
         tiny_f32.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"],
                              query=inp["query"], steps=3, cfg_scale=2.0)   # 1000//3 -> index 1000 (reference IndexError)
+    with pytest.raises(E.PdError, match="needs the noise draws"):   # the reference always draws noise when eta > 0
+        tiny_f32.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"],
+                             query=inp["query"], steps=4, cfg_scale=2.0, eta=0.5)
     e = E.Engine(W.TINY, precision="f32")
     with pytest.raises(E.PdError, match="not loaded"):
         e.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"],

@@ -176,4 +176,10 @@ def test_clip_text_transformer_matches_transformers(golden_dir, tag, cfg):
         assert relerr(z.reshape(-1)[::int(g["z_stride"])][:16384], g["z_sub"]) < 5e-5
     st = g["z_stats"]
     assert abs(float(np.abs(z).mean()) - st[1]) < 1e-4 * st[1]
+    # clip_skip = 2 as the (D) pipeline derives it: hidden_states[-3] through final_layer_norm (:403-413)
+    z2 = O.clip_text_forward(sd, cfg, ids, clip_skip=2)
+    if "z_skip2" in g:
+        assert relerr(z2, g["z_skip2"]) < 5e-5
+    else:
+        assert relerr(z2.reshape(-1)[::int(g["z_stride"])][:16384], g["z_skip2_sub"]) < 5e-5
 

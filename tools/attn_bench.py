@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from prompt_diffusion_amd import engine as E, weights as W
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-e = E.Engine(W.SD15, precision="bf16")
+e = E.Engine(W.SD15, precision=sys.argv[2] if len(sys.argv) > 2 else "f16")
 g = np.random.default_rng(0)
 q = g.standard_normal((16, 4096, 320), dtype=np.float32)
 k = g.standard_normal((16, 4096, 320), dtype=np.float32)

@@ -48,11 +48,13 @@ def main():
         seen = set()
         for r in rows:
             n = r.get("name", "")
-            if n in seen or flt not in n:
+            if n in seen:
                 continue
             seen.add(n)
             dem = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip()
             dem = re.sub(r"\(GemmParams\)|\(AttnParams\)|\(anonymous namespace\)::", "", dem)
+            if flt not in dem and flt not in n:
+                continue
             print(f"{dem[:110]:110s} vgpr {r.get('vgpr_count', '?'):>4s} agpr {r.get('agpr_count', '?'):>3s} sgpr {r.get('sgpr_count', '?'):>3s} "
                   f"lds {r.get('group_segment_fixed_size', '?'):>6s} scratch {r.get('private_segment_fixed_size', '?')}")
 
