@@ -212,9 +212,25 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         const int u = lc * 9 + tap;
         const int par = u & 1;
         const bool nextc = lc + 1 < nchunks;
-        if (tap == 0 && nextc) { load_piece(I0{}, c + 1); load_piece(I1{}, c + 1); load_piece(I2{}, c + 1); }
-        if (u + 1 < U) {
-            load_w(tap + 1 >= 9 ? c + 1 : c, tap + 1 >= 9 ? 0 : tap + 1);
+        // Request order matters: vmcnt retires in issue order, so the wait in front of store_w (bottom of the unit) also
+        // waits for every load issued BEFORE this unit's load_w.  The weight tile (L2-resident) is requested first and the
+        // HBM-latency patch pieces after it: a piece is then only waited for by the NEXT unit's store_w -- two units of
+        // MFMAs to land instead of one (round 1 issued the pieces first / at the bottom and stalled on HBM in 4 taps of 9).
+        // Every request below is UNCONDITIONAL (the last chunk / unit re-request addresses of their own that are never
+        // stored): hipcc's waitcnt insertion merges the counter state of both sides of a branch around a load, and a load
+        // that "may not have been issued" turns the counted vmcnt(N) in front of store_w into vmcnt(0) -- the stall again.
+        const int cn = nextc ? c + 1 : c;
+        load_w(tap + 1 >= 9 ? cn : c, tap + 1 >= 9 ? 0 : tap + 1);
+        // next chunk's patch (two halves through the same registers) -> the other patch buffer, last read in chunk c-1
+        {
+            const int nb = (lc + 1) & 1;
+            if constexpr (tap == 0) { load_piece(I0{}, cn); load_piece(I1{}, cn); load_piece(I2{}, cn); }
+            if constexpr (tap == 2) { if (nextc) store_one(I0{}, nb, cn); load_piece(I3{}, cn); }
+            if constexpr (tap == 3) { if (nextc) store_one(I1{}, nb, cn); load_piece(I4{}, cn); }
+            if constexpr (tap == 4) { if (nextc) store_one(I2{}, nb, cn); load_piece(I5{}, cn); }
+            if constexpr (tap == 5) { if (nextc) store_one(I3{}, nb, cn); }
+            if constexpr (tap == 6) { if (nextc) store_one(I4{}, nb, cn); }
+            if constexpr (tap == 7) { if (nextc) store_one(I5{}, nb, cn); }
         }
         const char* pa = sP + (lc & 1) * G::P_BYTES;
         const char* wa = sW + par * W_TILE;
@@ -241,16 +257,6 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
             }
         }
         if (u + 1 < U) store_w(par ^ 1);
-        // next chunk's patch (two halves through the same registers) -> the other patch buffer, last read in chunk c-1
-        if (nextc) {
-            const int nb = (lc + 1) & 1;
-            if constexpr (tap == 2) { store_one(I0{}, nb, c + 1); load_piece(I3{}, c + 1); }
-            if constexpr (tap == 3) { store_one(I1{}, nb, c + 1); load_piece(I4{}, c + 1); }
-            if constexpr (tap == 4) { store_one(I2{}, nb, c + 1); load_piece(I5{}, c + 1); }
-            if constexpr (tap == 5) store_one(I3{}, nb, c + 1);
-            if constexpr (tap == 6) store_one(I4{}, nb, c + 1);
-            if constexpr (tap == 7) store_one(I5{}, nb, c + 1);
-        }
         __syncthreads();
     };
     for (int c = 0; c < nchunks; ++c) {

@@ -655,7 +655,10 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     hipEvent_t mid = nullptr;
     if (profiling && !use_patch) { mid = next_event(); rec.klass = m.taps == 9 ? 0 : 1; }
     if (profiling && use_patch) rec.klass = 3;
-    if (use_patch ? launch_conv_patch(p, P, stream) : launch_gemm(p, P, stream, mid)) {
+    // second-generation (wave-specialised) patch kernel where it measures faster: many blocks per CU (its longer prologue
+    // amortises) or the split-K 16x16 level; the 2-round 64x64 launches stay on the first generation (152 vs 142 us)
+    const bool patch2 = use_patch && opt_patch2 && !f32 && !gn_coef && (patch_split > 1 || ptiles >= opt_patch2_tiles);
+    if (use_patch ? (patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream)) : launch_gemm(p, P, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;
     }

@@ -251,6 +251,8 @@ struct pd_engine {
     // lands on the MFMA waves and the halo is transformed 1.27x redundantly), so it is off by default.
     bool opt_gn_fuse = false;
     bool opt_patch = true;  // use the LDS-patch conv3x3 kernel where eligible
+    bool opt_patch2 = true; // 2-byte modes: the wave-specialised second-generation patch kernel (conv_patch2.hip)
+    int opt_patch2_tiles = 768;   // ... for launches of at least this many blocks (and every split-K patch launch)
     long long launches = 0;
     // optional per-launch timing (bench.py roofline leg): HIP events around every contraction launch
     struct ProfRec { hipEvent_t a, b; int klass; double flops; int M, N, K, taps; };

@@ -190,6 +190,7 @@ int gemm_tiles(int M, int N);
 int launch_splitk_finalize(const GemmParams& p, hipStream_t s);   // sums p.splitk fp32 slabs in slice order + epilogue
 int conv_patch_tiles(const GemmParams& p, int prec);  // 0: shape not eligible for the LDS-patch conv kernel
 int launch_conv_patch(const GemmParams& p, int prec, hipStream_t s);
+int launch_conv_patch2(const GemmParams& p, int prec, hipStream_t s);   // conv_patch2.hip: compute / loader wave specialisation (2-byte types)
 int launch_attention(const AttnParams& p, int prec, hipStream_t s);
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,

@@ -106,8 +106,8 @@ extern "C" int pd_text_weights_missing(pd_engine* e) {
 
 extern "C" int pd_text_encode_ex(pd_engine* e, const int32_t* ids, int32_t B, int32_t mem, int32_t clip_skip, float* out) {
     if (!e || !ids || !out || B < 1) { pd_set_error("bad argument"); return 1; }
-    if (clip_skip < 0 || (e->text.built && clip_skip >= (int)e->text.layers.size())) {
-        pd_set_error("clip_skip %d out of range [0, %d)", clip_skip, e->cfg.text_layers);
+    if (clip_skip < 0 || (e->text.built && clip_skip > (int)e->text.layers.size())) {   // k = text_layers: hidden_states[0], the embeddings
+        pd_set_error("clip_skip %d out of range [0, %d]", clip_skip, e->cfg.text_layers);
         return 1;
     }
     if (!e->text.built) { pd_set_error("this engine was created without a text transformer (text_layers = 0)"); return 1; }

@@ -32,7 +32,8 @@ class _Stop(Exception):
 def _first_steps(prec, inputs, steps=3):
     """the first `steps` UniPC steps of the 20-step schedule through the (D) pipeline surface"""
     e = E.Engine(W.SD15, precision=prec)
-    e.init_random_weights(777)
+    for n, arr in W.iter_synth(W.SD15):     # the fixtures' seeded recipe
+        e.load_tensor(n, arr)
     pipe = PromptDiffusionPipeline(e, scheduler=UniPCMultistepScheduler())
     a, b = inputs["pair"][:, :3], inputs["pair"][:, 3:]
     lats = []

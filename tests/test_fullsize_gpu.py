@@ -121,7 +121,8 @@ def test_headline_size_per_step_error_vs_fp32_engine(inputs):
     traj = {}
     for prec in ("f32", "f16", "bf16"):
         e = E.Engine(W.SD15, precision=prec)
-        e.init_random_weights(4321)
+        for n, a in W.iter_synth(W.SD15):      # the fixtures' seeded recipe (the device-side random init is a far more
+            e.load_tensor(n, a)                # sensitive network: fine for invariances, meaningless for an error figure)
         e.sample_begin(**kw)
         xs = []
         for i in range(3):

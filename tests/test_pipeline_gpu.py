@@ -267,6 +267,6 @@ def test_pipeline_from_prompts_with_engine_text_encoder():
         ref1 = pipe(prompt_embeds=pe1, negative_prompt_embeds=ne, **kw).images
         assert relerr(out1, ref1) < 2e-4 and relerr(out1, out) > 1e-3
         with pytest.raises(E.PdError, match="clip_skip"):
-            pipe(prompt=prompts, clip_skip=cfg.text_layers, **kw)
+            pipe(prompt=prompts, clip_skip=cfg.text_layers + 1, **kw)
     finally:
         e.close()
