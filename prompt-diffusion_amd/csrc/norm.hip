@@ -90,15 +90,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
     constexpr bool XF32 = XD == DT_F32, YF32 = YD == DT_F32;
     constexpr int VEC = XF32 ? 4 : 8;  // elements per 16-byte input vector
     __shared__ float s_mean[64], s_rstd[64];
+    __shared__ double s_part[4][64][2];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
-    if (tid < groups) {
-        double s = 0.0, q = 0.0;
-        for (int c = 0; c < nchunk; ++c) {
-            const double* o = partial + (((size_t)b * nchunk + c) * groups + tid) * 2;
-            s += o[0];
-            q += o[1];
+    // fold the chunk partials: 4 threads per group each sum a quarter of the chunks (every block repeats this fold, so
+    // its serial length -- 64 dependent fp64 loads in round 1 -- sat in front of every block's few pixels), then a
+    // fixed-order sum of the 4 quarters: deterministic
+    {
+        const int g = tid & 63, part = tid >> 6;
+        if (g < groups) {
+            double s = 0.0, q = 0.0;
+            for (int c = part; c < nchunk; c += 4) {
+                const double* o = partial + (((size_t)b * nchunk + c) * groups + g) * 2;
+                s += o[0];
+                q += o[1];
+            }
+            s_part[part][g][0] = s;
+            s_part[part][g][1] = q;
         }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const double s = (s_part[0][tid][0] + s_part[1][tid][0]) + (s_part[2][tid][0] + s_part[3][tid][0]);
+        const double q = (s_part[0][tid][1] + s_part[1][tid][1]) + (s_part[2][tid][1] + s_part[3][tid][1]);
         const double n = (double)HW * (double)(C / groups);
         const double mean = s / n;
         double var = q / n - mean * mean;
@@ -403,9 +417,9 @@ int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int
 
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
                     const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s) {
-    // pixel slabs per sample: aim at >= 2048 blocks, at least 4 pixels per thread row
-    int napply = (2048 + B - 1) / B;
-    if (napply > HW / 4) napply = HW / 4;
+    // pixel slabs per sample: aim at >= 1024 blocks, at least 16 pixels per thread row (every block folds the statistics)
+    int napply = (1024 + B - 1) / B;
+    if (napply > HW / 16) napply = HW / 16;
     if (napply < 1) napply = 1;
     dim3 grid(napply, B);
     const bool ok = dispatch_xy(x_dt, y_dt, [&](auto XD, auto YD) {

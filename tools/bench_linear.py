@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from prompt_diffusion_amd import engine as E, weights as W
 ap = argparse.ArgumentParser(); ap.add_argument("--opt", action="append", default=[])
 a = ap.parse_args()
-e = E.Engine(W.SD15, precision="bf16")
+e = E.Engine(W.SD15, precision="f16")
 for o in a.opt:
     k, v = o.split("="); e.set_option(k, int(v))
 shapes = [(65536, 320, 320, 0), (65536, 320, 320, 1), (65536, 320, 960, 0), (65536, 1280, 320, 1), (16384, 640, 640, 0), (16384, 640, 640, 1),
