@@ -191,6 +191,8 @@ int pd_wait_stream(pd_engine* e, void* producer);
  *   "graph" (pd_ddim_sample captures its step loop in a hipGraph and replays it on later calls with equal arguments, 0),
  *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "conv_patch2" (its wave-specialised second generation in the 2-byte modes, 1), "patch_split" / "patch_split_tiles" (that kernel with the channel chunks
  *   split over 2-4 slices when it has fewer tiles than CUs but at least this many, 1 / 64), "gn_fuse" (GroupNorm applied while the patch is staged, 0),
+ *   "ln_fuse" (norm1 / norm2 of a transformer block folded into the to_q/k/v and attn2.to_q GEMMs, row statistics carried
+ *   from the producing GEMM's epilogue: -1 = on in the 2-byte modes and off in the fp32-storage modes, 0 / 1 forced),
  *   "gn_single" (single-kernel LDS-slab GroupNorm where a sample's group bundle fits, 1),
  *   "big_tile" / "wide_tile" (256x160 / 256x320 GEMM tiles, 1), "dense_k" / "dense_tiles" (8-wave unsplit tile for
  *   linear layers with at most that many K steps, 40 / 128), "short_k" (8-wave 128x160 tile at 16 waves per CU for

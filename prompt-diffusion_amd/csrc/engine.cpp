@@ -428,6 +428,7 @@ int pd_engine::load(const char* name, const void* data, const int64_t* shape, in
     if (p.kind == 0) {
         PD_TRY(upload_vec(p.vdst, src.data(), (int)n, p.geglu_vec, p.geglu_half));
         p.loaded = true;
+        ln_dirty = true;
         return 0;
     }
     WMat& m = *p.mat;
@@ -441,6 +442,7 @@ int pd_engine::load(const char* name, const void* data, const int64_t* shape, in
     }
     PD_TRY(upload_rows(m, p.row_off, src.data(), rows, p.conv));
     p.loaded = true;
+    ln_dirty = true;
     return 0;
 }
 
@@ -516,6 +518,37 @@ int pd_engine::init_random(uint64_t seed) {
         p.loaded = true;
     }
     HIP_OK(hipStreamSynchronize(stream));
+    ln_dirty = true;
+    return 0;
+}
+
+// LayerNorm folded into its consumer (attention.py:271-275: x + attn1(norm1(x)), + attn2(norm2(x)), + ff(norm3(x))):
+// LN(x) . W^T = rstd * (x . (W diag(gamma))^T - mean * colsum) + beta . W^T, so the consumer GEMM reads the residual stream
+// itself and the normalised tensor is never written.  Built once per weight change.
+int pd_engine::fold_layernorms() {
+    const bool on = opt_ln_fuse < 0 ? !f32 : opt_ln_fuse != 0;
+    if (!on || !ln_dirty) return 0;
+    for (int which = 0; which < 2; ++which) {
+        NetW& net = which ? cnet : unet;
+        for (STW* st : net.st_list) {
+            WMat* mats[2] = {&st->qkv, &st->q2};   // norm1 -> to_q/k/v, norm2 -> attn2.to_q; norm3 (GEGLU tile) stays a kernel
+            for (int i = 0; i < 2; ++i) {
+                WMat& m = *mats[i];
+                if (!m.w_ln) {
+                    m.w_ln = dmalloc((size_t)m.N * m.Kpad * dt_size(T));
+                    m.colsum = reinterpret_cast<float*>(dmalloc((size_t)(m.N + 4) * sizeof(float)));
+                    m.bias_ln = reinterpret_cast<float*>(dmalloc((size_t)(m.N + 4) * sizeof(float)));
+                    if (!m.w_ln || !m.colsum || !m.bias_ln) { pd_set_error("allocation of folded LayerNorm weights failed"); return 1; }
+                }
+                if (launch_ln_fold(m.w, m.w_ln, T, m.N, m.K, m.Kpad, st->ln_g[i], st->ln_b[i], m.bias, m.colsum, m.bias_ln, stream)) {
+                    pd_set_error("LayerNorm fold launch failed");
+                    return 1;
+                }
+            }
+        }
+    }
+    HIP_OK(hipStreamSynchronize(stream));
+    ln_dirty = false;
     return 0;
 }
 
@@ -550,7 +583,7 @@ Act pd_engine::new_act(int B, int H, int W, int C, int dt) {
 
 int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups, int act, float scale, const Act* R,
                     const float* rowvec, int rowvec_stride, bool a_silu, void* VT, int vt_begin, int vt_ld, int ldc_override,
-                    const float* gn_coef, bool gn_silu) {
+                    const float* gn_coef, bool gn_silu, const LnStats* ln_in, LnStats* ln_out) {
     if (in.C != m.cin_pad) {
         pd_set_error("gemm: input has %d channels, layer expects %d", in.C, m.cin_pad);
         return 1;
@@ -579,6 +612,16 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.slab = nullptr;
     p.gn_coef = gn_coef;
     p.gn_silu = gn_silu ? 1 : 0;
+    if (ln_in) {   // LayerNorm of `in` folded into this layer: raw A, folded weights, statistics from the producer
+        if (!m.w_ln) { pd_set_error("internal: folded LayerNorm weights missing"); return 1; }
+        p.W = m.w_ln;
+        p.bias = m.bias_ln;
+        p.ln_stats = ln_in->stats;
+        p.ln_parts = ln_in->parts;
+        p.ln_colsum = m.colsum;
+        p.ln_C = ln_in->C;
+        p.ln_eps = 1e-5f;
+    }
     // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
     const int ptiles = opt_patch ? conv_patch_tiles(p, P) : 0;
     bool use_patch = ptiles >= 192;
@@ -630,6 +673,13 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         // 128 x 160 tile on 8 waves at <= 128 VGPRs runs 2 blocks = 16 waves per CU (+0.6 % end-to-end, interleaved A/B)
         if (opt_short_k > 0 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_short_k) p.big_tile = 2;
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
+        if (ln_out && splitk == 1 && !m.geglu && !VT) {   // this launch's own epilogue leaves the row statistics
+            const int bn_cols = p.big_tile == 3 ? 320 : 160;
+            ln_out->parts = ((m.N + bn_cols - 1) / bn_cols) * 2;   // 2 waves across N in every non-GEGLU tile
+            ln_out->C = m.Nout;
+            p.stats_out = ln_out->stats;
+            p.stats_parts = ln_out->parts;
+        }
     }
     if (use_patch && patch_split > 1) {
         const size_t mk = arena.mark();
@@ -665,6 +715,15 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     if (profiling) {
         if (mid) { rec.b = mid; prof.push_back(rec); }   // bracket = the contraction kernel only (no split-K finalize)
         else prof_end(rec);
+    }
+    if (ln_out && !p.stats_out) {   // split-K / patch launches finish in another kernel: one statistics pass over the output
+        ln_out->parts = 1;
+        ln_out->C = m.Nout;
+        ++launches;
+        if (launch_row_stats(out.p, out.dt, ln_out->stats, (int)out.rows(), out.C, stream)) {
+            pd_set_error("row statistics launch failed");
+            return 1;
+        }
     }
     return 0;
 }
@@ -810,29 +869,42 @@ int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& k
     const size_t mk = arena.mark();
     Act a = new_act(B, H, W, C, T);
     PD_TRY(groupnorm(x, a, s.gn_g, s.gn_b, 1e-6f, false));
+    const bool fuse = (opt_ln_fuse < 0 ? !f32 : opt_ln_fuse != 0) && s.qkv.w_ln != nullptr;
+    // LayerNorm statistics travel from the epilogue that writes h / h1 / h2 to the GEMM that consumes norm1/2/3 of it
+    // (fold_layernorms): at most 16 column-range partials per row
+    LnStats st0, st1;
+    if (fuse) {
+        const size_t cap = (size_t)B * N * 16 * 2 * sizeof(float);
+        st0.stats = reinterpret_cast<float*>(arena.alloc(cap));
+        st1.stats = reinterpret_cast<float*>(arena.alloc(cap));
+    }
     Act h = new_act(B, H, W, C, S);
-    PD_TRY(conv(s.proj_in, a, h));
+    PD_TRY(gemm(s.proj_in.m, a, h, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0, 0, nullptr, false, nullptr, fuse ? &st0 : nullptr));
     // self-attention: fused QKV projection; V stored transposed for the attention kernel
-    Act ln = new_act(B, H, W, C, T);
-    PD_TRY(layernorm(h, ln, s.ln_g[0], s.ln_b[0]));
+    Act ln;
+    if (!fuse) {
+        ln = new_act(B, H, W, C, T);
+        PD_TRY(layernorm(h, ln, s.ln_g[0], s.ln_b[0]));
+    }
     Act qk = new_act(B, H, W, 2 * C, T);
     const int npad = round_up(N, 8);
     Act vt = new_act(B, C, 1, npad, T);
-    PD_TRY(gemm(s.qkv, ln, qk, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * C, npad));
+    PD_TRY(gemm(s.qkv, fuse ? h : ln, qk, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * C, npad, 0, nullptr, false, fuse ? &st0 : nullptr));
     Act att = new_act(B, H, W, C, T);
     const size_t eb = dt_size(T);
     PD_TRY(attention(qk.p, 2 * C, reinterpret_cast<char*>(qk.p) + (size_t)C * eb, 2 * C, vt.p, npad, att.p, C, B, N, N, C));
     Act h1 = new_act(B, H, W, C, S);
-    PD_TRY(gemm(s.out1, att, h1, 1, 0, 0, 1.f, &h, nullptr, 0, false, nullptr, 0, 0));
+    PD_TRY(gemm(s.out1, att, h1, 1, 0, 0, 1.f, &h, nullptr, 0, false, nullptr, 0, 0, 0, nullptr, false, nullptr, fuse ? &st1 : nullptr));
     // cross-attention against the hoisted context K / V^T
-    PD_TRY(layernorm(h1, ln, s.ln_g[1], s.ln_b[1]));
+    if (!fuse) PD_TRY(layernorm(h1, ln, s.ln_g[1], s.ln_b[1]));
     Act q2 = new_act(B, H, W, C, T);
-    PD_TRY(gemm(s.q2, ln, q2, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
+    PD_TRY(gemm(s.q2, fuse ? h1 : ln, q2, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0, 0, nullptr, false, fuse ? &st1 : nullptr));
     const int L = cfg.context_len, lpad = round_up(L, 8);
     PD_TRY(attention(q2.p, C, kv.K, C, kv.VT, lpad, att.p, C, B, N, L, C));
     Act h2 = new_act(B, H, W, C, S);
     PD_TRY(gemm(s.out2, att, h2, 1, 0, 0, 1.f, &h1, nullptr, 0, false, nullptr, 0, 0));
-    // GEGLU feed-forward
+    // GEGLU feed-forward (norm3 as a kernel: see fold_layernorms)
+    if (fuse) ln = new_act(B, H, W, C, T);
     PD_TRY(layernorm(h2, ln, s.ln_g[2], s.ln_b[2]));
     Act g = new_act(B, H, W, 4 * C, T);
     PD_TRY(gemm(s.ff1, ln, g, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));

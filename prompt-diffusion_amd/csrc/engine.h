@@ -37,6 +37,17 @@ struct WMat {
     int cin = 0, cin_pad = 0;
     int fan_in = 1;
     bool geglu = false;
+    // LayerNorm folded into this layer (pd_engine::fold_layernorms): W * diag(gamma), its column sums, bias + beta . W^T
+    void* w_ln = nullptr;
+    float* colsum = nullptr;
+    float* bias_ln = nullptr;
+};
+
+// LayerNorm statistics handed from the GEMM that writes a residual-stream tensor to the GEMM that consumes its LayerNorm
+struct LnStats {
+    float* stats = nullptr;   // [rows][parts][2] {sum, sum of squares}
+    int parts = 0;
+    int C = 0;
 };
 
 struct ConvW {
@@ -297,7 +308,10 @@ struct pd_engine {
     Act new_act(int B, int H, int W, int C, int dt);
     int gemm(const WMat& m, const Act& in, Act& out, int taps_stride, int ups, int act, float scale, const Act* R,
              const float* rowvec, int rowvec_stride, bool a_silu, void* VT, int vt_begin, int vt_ld, int ldc_override = 0,
-             const float* gn_coef = nullptr, bool gn_silu = false);
+             const float* gn_coef = nullptr, bool gn_silu = false, const LnStats* ln_in = nullptr, LnStats* ln_out = nullptr);
+    int fold_layernorms();     // (re)builds the folded weights of every transformer block after a weight change
+    bool ln_dirty = true;
+    int opt_ln_fuse = -1;      // -1: on in the 2-byte modes, off in the fp32-storage modes; 0 / 1: forced
     int gn_stats(const Act& x, int& nchunk);
     int conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, const float* b, float eps, bool silu, const Act* R,
                 const float* rowvec, int rowvec_stride);

@@ -105,6 +105,18 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
         w_ptr[i] = reinterpret_cast<const char*>(p.W) + ((size_t)n * (p.ldw ? p.ldw : p.Kpad) + chunk * VEC) * EB;
     }
 
+    // folded LayerNorm: {mean, rstd} of this block's BM rows, combined once from the producer's partials into LDS behind the
+    // staging buffers (the epilogue reads two floats per row instead of walking the partials in every lane)
+    constexpr bool LNF = !(NT % 10 == 0 && WN == 1);   // not on the GEGLU-capable tiles: see the epilogue
+    float2* sLn = reinterpret_cast<float2*>(smem + 2 * (BM + BN) * BKB);
+    if constexpr (LNF) {
+        if (p.ln_stats && tid < BM) {
+            const int gm = bm * BM + tid;
+            float mean = 0.f, rstd = 0.f;
+            if (gm < p.M) ln_row_stats(p, gm, mean, rstd);
+            sLn[tid] = make_float2(mean, rstd);
+        }
+    }
     const int ktiles_all = p.Kpad / BKE;
     int kt0 = 0, kt1 = ktiles_all;
     if (p.splitk > 1) {
@@ -344,6 +356,16 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
         if (gm >= p.M) continue;
         const int sample = gm / p.rows_per_sample;
         const int tok = gm - sample * p.rows_per_sample;
+        // folded LayerNorm / row statistics: every tile except the GEGLU-capable ones (8 x 1 waves, 160 accumulator
+        // registers at the VGPR cap: the extra epilogue state spills their accumulators -- norm3 stays a kernel of its own)
+        float ln_mean = 0.f, ln_rstd = 0.f;
+        if constexpr (LNF) {
+            if (p.ln_stats) {
+                const float2 t = sLn[wm * WTM + m * 16 + fr];
+                ln_mean = t.x;
+                ln_rstd = t.y;
+            }
+        }
         if (p.act == 2) {
             // GEGLU: virtual columns [0,80) of this tile are x, [80,160) the gate (weights interleaved at load)
             if constexpr (NT % 10 == 0 && WN == 1) {
@@ -368,11 +390,27 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             }
             continue;
         }
+        float rs = 0.f, rq = 0.f;   // producer side: this row's {sum, sum of squares} over the wave's column range
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
             if (gn >= p.N) continue;
-            epilogue4(p, gm, gn, sample, tok, acc[n][m]);
+            const f32x4 v = epilogue4(p, gm, gn, sample, tok, acc[n][m], ln_mean, ln_rstd);
+            if constexpr (LNF) {
+                if (p.stats_out) {
+                    rs += (v[0] + v[1]) + (v[2] + v[3]);
+                    rq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+            }
+        }
+        if (LNF && p.stats_out) {   // the row's 4 lane quarters (fq) hold disjoint channels: fold them, lane quarter 0 writes
+            rs += __shfl_xor(rs, 16); rq += __shfl_xor(rq, 16);
+            rs += __shfl_xor(rs, 32); rq += __shfl_xor(rq, 32);
+            if (fq == 0) {
+                float* o = p.stats_out + ((size_t)gm * p.stats_parts + bn * WN + wn) * 2;
+                o[0] = rs;
+                o[1] = rq;
+            }
         }
     }
 }
@@ -388,14 +426,16 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + (size_t)gm * p.N + gn);
         for (int s = 1; s < p.splitk; ++s) v += *reinterpret_cast<const f32x4*>(slab + ((size_t)s * p.M + gm) * p.N + gn);
         const int sample = gm / p.rows_per_sample;
-        epilogue4(p, gm, gn, sample, gm - sample * p.rows_per_sample, v);
+        float ln_mean = 0.f, ln_rstd = 0.f;
+        if (p.ln_stats) ln_row_stats(p, gm, ln_mean, ln_rstd);
+        epilogue4(p, gm, gn, sample, gm - sample * p.rows_per_sample, v, ln_mean, ln_rstd);
     }
 }
 
 template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
 int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr int NTHREADS = WM * WN * 64;
-    constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB;
+    constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB + BM * 8;   // staging buffers + {mean, rstd} of the block's rows
     static unsigned long long attr_done = 0;
     auto kfn = igemm_kernel<P, BM, BN, WM, WN, CONV, AF32>;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM_BYTES, &attr_done)) return 1;
@@ -435,7 +475,7 @@ int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     const bool af32 = !F && p.a_dt == DT_F32;          // 2-byte compute reading an fp32 A (converted while staging)
     const int tile = p.splitk == 1 ? p.big_tile : 0;   // 0: 128x160, 1: 256x160, 2: 128x160 on 8 waves, 3: 256x320
     if (p.act == 2) {
-        if (conv || af32) return 1;
+        if (conv || af32 || p.ln_stats || p.stats_out) return 1;
         if (tile == 3) return launch_one<P, 256, 320, 8, 1, false, false>(p, s, mid);
         if (tile == 1) return launch_one<P, 256, 160, 8, 1, false, false>(p, s, mid);
         return launch_one<P, 128, 160, 4, 1, false, false>(p, s, mid);

@@ -383,6 +383,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     }
 }
 
+// {sum, sum of squares} of each row (one wave per row): LayerNorm statistics for the GEMMs that fold the normalisation
+template <int XD>
+__global__ __launch_bounds__(256) void row_stats_kernel(const void* __restrict__ x, float* __restrict__ stats, int rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f, q = 0.f;
+    for (int v = lane; v < C / 4; v += 64) {
+        const f32x4 t = load4(x, (size_t)row * C + (size_t)v * 4, XD);
+        s += (t[0] + t[1]) + (t[2] + t[3]);
+        q += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane == 0) { stats[(size_t)row * 2] = s; stats[(size_t)row * 2 + 1] = q; }
+}
+
+// LayerNorm folded into the consumer's weights (one wave per weight row n, fixed summation order):
+//   Wout[n][k] = round_T(W[n][k] * gamma[k]),  colsum[n] = sum_k Wout[n][k],  bias_out[n] = bias_in[n] + sum_k beta[k] * W[n][k]
+template <int DT>
+__global__ __launch_bounds__(256) void ln_fold_kernel(const void* __restrict__ W, void* __restrict__ Wout, int N, int K, int Kpad,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias_in, float* __restrict__ colsum,
+                                                      float* __restrict__ bias_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float cs = 0.f, bs = 0.f;
+    for (int k = lane; k < Kpad; k += 64) {
+        float w, wg = 0.f;
+        const size_t i = (size_t)n * Kpad + k;
+        if constexpr (DT == DT_F32) w = reinterpret_cast<const float*>(W)[i];
+        else w = cvt32<DT>(reinterpret_cast<const uint16_t*>(W)[i]);
+        if (k < K) {
+            wg = w * gamma[k];
+            bs += beta[k] * w;
+        }
+        if constexpr (DT == DT_F32) {
+            reinterpret_cast<float*>(Wout)[i] = wg;
+        } else {
+            const uint16_t r = cvt16<DT>(wg);
+            reinterpret_cast<uint16_t*>(Wout)[i] = r;
+            wg = cvt32<DT>(r);      // the column sum must be that of the weights the MFMA will see
+        }
+        cs += wg;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cs += __shfl_xor(cs, o); bs += __shfl_xor(bs, o); }
+    if (lane == 0) {
+        colsum[n] = cs;
+        bias_out[n] = (bias_in ? bias_in[n] : 0.f) + bs;
+    }
+}
+
 // calls f(integral_constant<XD>, integral_constant<YD>) for the (input, output) type pairs the engine produces:
 // fp32 on either side, or the same 2-byte flavour on both
 template <typename F>
@@ -461,6 +515,24 @@ int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gam
 int launch_gn_coef(const double* partial, const float* gamma, const float* beta, float* coef, int B, int HW, int C, int groups,
                    int nchunk, float eps, hipStream_t s) {
     hipLaunchKernelGGL(gn_coef_kernel, dim3(B), dim3(256), 0, s, partial, gamma, beta, coef, HW, C, groups, nchunk, eps);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_row_stats(const void* x, int x_dt, float* stats, int rows, int C, hipStream_t s) {
+    if (C % 4) return 1;
+    dim3 grid((rows + 3) / 4);
+    if (x_dt == DT_F32) hipLaunchKernelGGL(row_stats_kernel<DT_F32>, grid, dim3(256), 0, s, x, stats, rows, C);
+    else if (x_dt == DT_F16) hipLaunchKernelGGL(row_stats_kernel<DT_F16>, grid, dim3(256), 0, s, x, stats, rows, C);
+    else hipLaunchKernelGGL(row_stats_kernel<DT_BF16>, grid, dim3(256), 0, s, x, stats, rows, C);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_ln_fold(const void* W, void* Wout, int dt, int N, int K, int Kpad, const float* gamma, const float* beta, const float* bias_in,
+                   float* colsum, float* bias_out, hipStream_t s) {
+    dim3 grid((N + 3) / 4);
+    if (dt == DT_F32) hipLaunchKernelGGL(ln_fold_kernel<DT_F32>, grid, dim3(256), 0, s, W, Wout, N, K, Kpad, gamma, beta, bias_in, colsum, bias_out);
+    else if (dt == DT_F16) hipLaunchKernelGGL(ln_fold_kernel<DT_F16>, grid, dim3(256), 0, s, W, Wout, N, K, Kpad, gamma, beta, bias_in, colsum, bias_out);
+    else hipLaunchKernelGGL(ln_fold_kernel<DT_BF16>, grid, dim3(256), 0, s, W, Wout, N, K, Kpad, gamma, beta, bias_in, colsum, bias_out);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

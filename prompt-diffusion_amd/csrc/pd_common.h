@@ -170,6 +170,18 @@ struct GemmParams {
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;
     int ldw;              // weight row stride in elements (0: Kpad) -- lets a device activation act as the W operand
+    // LayerNorm folded into this GEMM (consumer side): A is the RAW residual-stream tensor, W holds W * diag(gamma), and the
+    // epilogue turns acc = x . W'^T into LN(x) . W^T = rstd[m] * (acc - mean[m] * colsum[n]) (+ bias, which carries beta . W^T).
+    // ln_stats: [M][ln_parts][2] fp32 {sum, sum of squares} partials of each row of A over disjoint column ranges.
+    const float* ln_stats;
+    const float* ln_colsum;   // [N] sum_k W'[n][k] of the stored (rounded) weights
+    int ln_parts;
+    int ln_C;                 // row length of A (number of normalised channels)
+    float ln_eps;
+    // producer side: this GEMM writes a residual-stream tensor that a LayerNorm reads next -- every (row, column range of
+    // one wave) leaves its {sum, sum of squares} in stats_out[M][stats_parts][2] (igemm_kernel epilogue only)
+    float* stats_out;
+    int stats_parts;
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
@@ -200,6 +212,12 @@ int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gam
                     float eps, int do_silu, hipStream_t s);
 int launch_gn_coef(const double* partial, const float* gamma, const float* beta, float* coef, int B, int HW, int C, int groups,
                    int nchunk, float eps, hipStream_t s);
+// {sum, sum of squares} of every row: the single-part form of the LayerNorm statistics above (producers whose epilogue
+// cannot emit them: split-K finalize, patch conv)
+int launch_row_stats(const void* x, int x_dt, float* stats, int rows, int C, hipStream_t s);
+// W' = W * diag(gamma) in the compute type, colsum[n] = sum_k W'[n][k], bias_out[n] = bias_in[n] + sum_k beta[k] * W[n][k]
+int launch_ln_fold(const void* W, void* Wout, int dt, int N, int K, int Kpad, const float* gamma, const float* beta, const float* bias_in,
+                   float* colsum, float* bias_out, hipStream_t s);
 int launch_layernorm(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta,
                      int rows, int C, float eps, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, void* out, int out_dt, int B, int C, int H, int W, int Cpad, hipStream_t s,

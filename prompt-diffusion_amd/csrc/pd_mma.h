@@ -93,8 +93,34 @@ __device__ __forceinline__ uint4 cvt8(const uint4& lo, const uint4& hi, bool do_
     return pack8<P>(f);
 }
 
-// bias / time-embedding row / activation / scale / residual / (transposed) store of 4 consecutive channels
-__device__ __forceinline__ void epilogue4(const GemmParams& p, int gm, int gn, int sample, int tok, f32x4 v) {
+// LayerNorm statistics of row gm of a folded GEMM's A operand: {mean, rstd} from the producer's column-range partials
+__device__ __forceinline__ void ln_row_stats(const GemmParams& p, int gm, float& mean, float& rstd) {
+    // fp32 is enough here: <= 16 partials of <= 1280 channels each, and var = E[x^2] - mean^2 loses precision only when
+    // |mean| >> std (relative error ~ 1e-7 * mean^2 / var); the residual stream this normalises is far from that regime
+    float s = 0.f, q = 0.f;
+    const float* st = p.ln_stats + (size_t)gm * p.ln_parts * 2;
+    for (int i = 0; i < p.ln_parts; ++i) {
+        const float2 t = *reinterpret_cast<const float2*>(st + 2 * i);
+        s += t.x;
+        q += t.y;
+    }
+    const float inv = __builtin_amdgcn_rcpf((float)p.ln_C);
+    mean = s * inv;
+    const float var = fmaxf(q * inv - mean * mean, 0.f);
+    rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+}
+__device__ __forceinline__ f32x4 ln_apply4(const GemmParams& p, int gn, f32x4 v, float mean, float rstd) {
+    const f32x4 cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + gn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = rstd * (v[j] - mean * cs[j]);
+    return v;
+}
+
+// (folded LayerNorm) / bias / time-embedding row / activation / scale / residual / (transposed) store of 4 consecutive
+// channels; returns the value stored (before rounding to the output type)
+__device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, int sample, int tok, f32x4 v, float ln_mean = 0.f,
+                                           float ln_rstd = 0.f) {
+    if (p.ln_stats) v = ln_apply4(p, gn, v, ln_mean, ln_rstd);
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + gn);
     if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (size_t)sample * p.rowvec_stride + gn);
     if (p.act == 1) {
@@ -121,5 +147,6 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int gm, int gn, i
     } else {
         store4(p.C, (size_t)gm * p.ldc + gn, p.c_dt, v);
     }
+    return v;
 }
 

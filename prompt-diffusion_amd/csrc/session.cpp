@@ -302,6 +302,7 @@ static int check_args(pd_engine* e, const pd_sample_args* a) {
 int pd_engine::begin(const pd_sample_args* a, bool want_per_step) {
     PD_TRY(check_args(this, a));
     HIP_OK(hipSetDevice(device));
+    PD_TRY(fold_layernorms());
     ses.active = false;
     ses.a = *a;
     ses.Bf = a->use_cfg ? 2 * a->batch : a->batch;
@@ -548,6 +549,7 @@ int pd_eps(pd_engine* e, const float* x, const int64_t* t, const float* ctx, con
     a.mem = mem; a.x_T = x; a.ctx_cond = ctx; a.pair = pair; a.query = query; a.control_scales = scales;
     PD_TRY(check_args(e, &a));
     HIP_OK(hipSetDevice(e->device));
+    PD_TRY(e->fold_layernorms());
     std::vector<int64_t> th(Bf);
     if (mem == PD_MEM_DEVICE) HIP_OK(hipMemcpy(th.data(), t, (size_t)Bf * 8, hipMemcpyDeviceToHost));
     else memcpy(th.data(), t, (size_t)Bf * 8);
@@ -722,6 +724,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "splitk_tiles")) { e->opt_splitk_tiles = (int)value; return 0; }
     if (!strcmp(key, "attn_legacy")) { e->opt_attn_legacy = value != 0; return 0; }
     if (!strcmp(key, "gn_fuse")) { e->opt_gn_fuse = value != 0; return 0; }
+    if (!strcmp(key, "ln_fuse")) { e->opt_ln_fuse = (int)value; e->ln_dirty = true; return 0; }
     if (!strcmp(key, "two_streams")) { e->opt_two_streams = value != 0; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }

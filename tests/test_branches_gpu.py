@@ -101,3 +101,29 @@ def test_stream_f32_option(golden_dir, prec, tol_plain, tol_stream):
         e.close()
     print(prec, "per-step latent error: plain %.2e, stream_f32 %.2e" % (errs[False], errs[True]))
     assert errs[False] < tol_plain and errs[True] < tol_stream and errs[True] < errs[False]
+
+
+@pytest.mark.parametrize("tag", ["tiny_b2_16x16_s5", "tiny_b1_8x24_s4"])
+def test_layernorm_fold_in_fp32_mode(golden_dir, tag):
+    """Option ln_fuse: norm1 and norm2 of a transformer block folded into their consumer GEMMs (weights * gamma,
+    rstd * (acc - mean * colsum) + beta . W^T in the epilogue, row statistics from the producing GEMM's epilogue or the
+    row-statistics kernel).  It is the default of the 2-byte modes; forced on in the fp32 mode it must reproduce the
+    reference's own run to the fp32 bound."""
+    g = np.load(os.path.join(golden_dir, f"net_{tag}.npz"))
+    B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
+    inp = W.synth_inputs(W.TINY, B, h, w)
+    e = E.Engine(W.TINY, precision="f32")
+    e.set_option("ln_fuse", 1)
+    e.load_state_dict(W.synth_state_dict(W.TINY))
+    n0 = e.stat("launches")
+    out, inter = e.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"],
+                               query=inp["query"], steps=S, cfg_scale=float(g["cfg_scale"]), return_intermediates=True)
+    n_fused = e.stat("launches") - n0
+    for i in range(S + 1):
+        assert relerr(inter[i], g["x_inter"][i]) < 2e-4, i
+    e.set_option("ln_fuse", 0)
+    n0 = e.stat("launches")
+    out2 = e.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"],
+                         query=inp["query"], steps=S, cfg_scale=float(g["cfg_scale"]))
+    assert relerr(out, out2) < 2e-4 and e.stat("launches") - n0 > n_fused     # the fold removes launches
+    e.close()

@@ -1,11 +1,11 @@
 """Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; each `--kernel-trace --pmc <counter> --output-format csv`) of
-a bench.py run into profiles/r01_pmc_traffic.json: HBM bytes per launch, per kernel family.
+a bench.py run into profiles/rNN_pmc_traffic.json: HBM bytes per launch, per kernel family.
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-byte request -> doubled; both
 counters are in KB.  usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> "<command that was profiled>" """
 import collections, csv, glob, json, sys
 
-FAMILIES = ("igemm_kernel<false", "conv3x3_patch_kernel<false", "attn2_kernel", "gn_apply_kernel<false", "gn_stats_kernel<false",
-            "layernorm_kernel<false", "splitk_finalize_kernel", "concat_add_kernel")
+FAMILIES = ("igemm_kernel<", "conv3x3_patch_kernel<", "conv3x3_patch2_kernel<", "attn2_kernel", "gn_apply_kernel<", "gn_stats_kernel<",
+            "gn_fused_kernel<", "layernorm_kernel<", "splitk_finalize_kernel", "concat_add_kernel")
 
 
 def collect(d, counter):
