@@ -37,7 +37,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row * BKB) + ((
 
 // P: compute type (DT_F32: fp32 MFMA mode; DT_BF16 / DT_F16: 2-byte operands).  CONV: 3x3 gather (else rows of A
 // are contiguous).  AF32: 2-byte compute with an fp32 A source (converted while staging; only meaningful when P != DT_F32).
-template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
+// GG: the GEGLU epilogue (act == 2) instead of the plain one -- a wave's WTN columns are whole [80 x | 80 gate] blocks.
+template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32, bool GG = false>
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) void igemm_kernel(GemmParams p) {
     constexpr bool F32 = prec_f32_storage(P);
     // register prefetch depth: two K steps ahead (two named staging sets) unless the fp32->bf16 staging
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
 
     // folded LayerNorm: {mean, rstd} of this block's BM rows, combined once from the producer's partials into LDS behind the
     // staging buffers (the epilogue reads two floats per row instead of walking the partials in every lane)
-    constexpr bool LNF = !(NT % 10 == 0 && WN == 1);   // not on the GEGLU-capable tiles: see the epilogue
+    constexpr bool LNF = !GG;   // not in the GEGLU instantiations (160 accumulator registers at the VGPR cap): norm3 stays a kernel
     float2* sLn = reinterpret_cast<float2*>(smem + 2 * (BM + BN) * BKB);
     if constexpr (LNF) {
         if (p.ln_stats && tid < BM) {
@@ -366,26 +367,25 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
                 ln_rstd = t.y;
             }
         }
-        if (p.act == 2) {
-            // GEGLU: virtual columns [0,80) of this tile are x, [80,160) the gate (weights interleaved at load)
-            if constexpr (NT % 10 == 0 && WN == 1) {
+        if constexpr (GG) {
+            // GEGLU: virtual columns [0,80) of each 160-column block are x, [80,160) the gate (weights interleaved at load)
+            static_assert(NT % 10 == 0, "a wave's columns must be whole 160-column GEGLU blocks");
 #pragma unroll
-                for (int sb = 0; sb < NT / 10; ++sb) {   // 160-column sub-blocks: [80 x | 80 gate]
+            for (int sb = 0; sb < NT / 10; ++sb) {
 #pragma unroll
-                    for (int n = 0; n < 5; ++n) {
-                        const int vn = bn * BN + sb * 160 + n * 16 + fq * 4;
-                        const int on = (bn * (BN / 160) + sb) * 80 + n * 16 + fq * 4;
-                        if (on >= p.Nout) continue;
-                        f32x4 x = acc[sb * 10 + n][m], g = acc[sb * 10 + n + 5][m];
-                        if (p.bias) {
-                            x += *reinterpret_cast<const f32x4*>(p.bias + vn);
-                            g += *reinterpret_cast<const f32x4*>(p.bias + vn + 80);
-                        }
-                        f32x4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = x[j] * (F32 ? gelu_f(g[j]) : gelu_fast(g[j]));
-                        store4(p.C, (size_t)gm * p.ldc + on, p.c_dt, o);
+                for (int n = 0; n < 5; ++n) {
+                    const int vn = bn * BN + wn * WTN + sb * 160 + n * 16 + fq * 4;
+                    const int on = ((bn * BN + wn * WTN) / 160 + sb) * 80 + n * 16 + fq * 4;
+                    if (on >= p.Nout) continue;
+                    f32x4 x = acc[sb * 10 + n][m], g = acc[sb * 10 + n + 5][m];
+                    if (p.bias) {
+                        x += *reinterpret_cast<const f32x4*>(p.bias + vn);
+                        g += *reinterpret_cast<const f32x4*>(p.bias + vn + 80);
                     }
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = x[j] * (F32 ? gelu_f(g[j]) : gelu_fast(g[j]));
+                    store4(p.C, (size_t)gm * p.ldc + on, p.c_dt, o);
                 }
             }
             continue;
@@ -432,12 +432,12 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
     }
 }
 
-template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32>
+template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32, bool GG = false>
 int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB + BM * 8;   // staging buffers + {mean, rstd} of the block's rows
     static unsigned long long attr_done = 0;
-    auto kfn = igemm_kernel<P, BM, BN, WM, WN, CONV, AF32>;
+    auto kfn = igemm_kernel<P, BM, BN, WM, WN, CONV, AF32, GG>;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM_BYTES, &attr_done)) return 1;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
     dim3 grid(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1);
@@ -476,9 +476,12 @@ int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     const int tile = p.splitk == 1 ? p.big_tile : 0;   // 0: 128x160, 1: 256x160, 2: 128x160 on 8 waves, 3: 256x320
     if (p.act == 2) {
         if (conv || af32 || p.ln_stats || p.stats_out) return 1;
-        if (tile == 3) return launch_one<P, 256, 320, 8, 1, false, false>(p, s, mid);
-        if (tile == 1) return launch_one<P, 256, 160, 8, 1, false, false>(p, s, mid);
-        return launch_one<P, 128, 160, 4, 1, false, false>(p, s, mid);
+        // 256 x 320 on 4 x 2 waves (wave tile 64 x 160 = one GEGLU block): 14 fragment reads per 40 MFMAs.  Round 1 ran it on
+        // 8 x 1 waves (32 x 320: 22 reads per 40 MFMAs, every wave re-reading all weight fragments), which made the tile
+        // LDS-read bound (352 KB per K step = 1375 LDS cycles against 1280 MFMA cycles).
+        if (tile == 3) return launch_one<P, 256, 320, 4, 2, false, false, true>(p, s, mid);
+        if (tile == 1) return launch_one<P, 256, 160, 8, 1, false, false, true>(p, s, mid);
+        return launch_one<P, 128, 160, 4, 1, false, false, true>(p, s, mid);
     }
     if constexpr (F) {   // fp32 mode: the 128x160 / 256x160 four-wave-group tiles only
         if (tile == 1 || tile == 3) return conv ? launch_one<P, 256, 160, 4, 2, true, false>(p, s, mid) : launch_one<P, 256, 160, 4, 2, false, false>(p, s, mid);
