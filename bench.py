@@ -286,6 +286,7 @@ def main():
                                   "algorithmic_bytes_per_launch": alg_per_launch,
                                   "traffic_over_algorithmic": (traffic / alg_per_launch) if traffic else None,
                                   "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,
+                                  "event_bracket_overhead_us": eng.stat("event_overhead_ns") / 1e3,
                                   "flop_per_launch": 1e9 * fl_g / max(n_g, 1), "device_ms_per_pass": ms_g, "by_kernel": classes}
         # first-stage decode of the 8 latents, outside the metric's timed region: reported for context
         try:

@@ -200,11 +200,13 @@ int pd_wait_stream(pd_engine* e, void* producer);
  *   "splitk_fused" (in-kernel split-K finalize, 0),
  *   "attn_legacy" (single-buffered attention kernel, 0). */
 int pd_set_option(pd_engine* e, const char* key, int64_t value);
-int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches", "steps" */
+int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches", "steps", "event_overhead_ns" */
 /* Per-launch timing: while option "profile" is 1 the engine brackets every contraction launch with HIP
  * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel on a conv1x1/linear,
  * 2 = attention, 3 = conv3x3_patch_kernel, -1 = all.  One bracket = one launch (split-K finalize excluded).
- * Returns summed device time, launch count and algorithmic FLOPs (2*M*N*K, logical channel counts). */
+ * Returns summed device time, launch count and algorithmic FLOPs (2*M*N*K, logical channel counts).  The elapsed time of
+ * a bracket around an empty one-block kernel, calibrated when "profile" is switched on (stat "event_overhead_ns"), is
+ * taken off every bracket. */
 int pd_profile_read(pd_engine* e, int32_t klass, double* total_ms, int64_t* n_launches, double* flops);
 int pd_profile_dump(pd_engine* e, const char* csv_path); /* one row per profiled launch */
 /* Micro-benchmark hook used by bench.py's roofline leg: times `iters` launches of the dominant

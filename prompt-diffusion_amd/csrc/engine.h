@@ -268,6 +268,7 @@ struct pd_engine {
     // optional per-launch timing (bench.py roofline leg): HIP events around every contraction launch
     struct ProfRec { hipEvent_t a, b; int klass; double flops; int M, N, K, taps; };
     bool profiling = false;
+    float prof_overhead_ms = 0.f;   // elapsed time of an EMPTY event bracket on this stream (calibrated when profiling is switched on)
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;

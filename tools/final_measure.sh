@@ -10,9 +10,10 @@ cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${R}_bench_kernel_sta
 grep -a '^{' $O/bench_under_rocprof.log | tail -1 > $O/${R}_bench_under_rocprof.json
 rm -rf $O/stats
 echo "[final] kernel stats done"
-# counters only for the contraction / attention / norm kernels: the unfiltered 31 000-dispatch trace crashes the profiler
-KRE="igemm_kernel|conv3x3_patch|attn2_kernel|gn_|layernorm|splitk_finalize|concat_add"
-PMC_CMD="python bench.py --single-stream --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-f32 --no-parity"
+# counters only for the contraction and attention kernels, on a 20-step sampling of the SAME workload (identical per-step
+# launches; 20 divides 1000 like 50 does): rocprofv3 segfaults beyond roughly 10 000 profiled dispatches (50 steps: 13 000)
+KRE="igemm_kernel|conv3x3_patch|attn2_kernel"
+PMC_CMD="python bench.py --single-stream --steps 1 --warmup 0 --ddim-steps 20 --no-cpu-baseline --no-profile --no-f32 --no-parity"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$KRE" --output-format csv -d $O/fetch -- $PMC_CMD > $O/fetch.log 2>&1
 echo "[final] FETCH_SIZE pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$KRE" --output-format csv -d $O/write -- $PMC_CMD > $O/write.log 2>&1
