@@ -31,8 +31,8 @@ extern "C" {
 #define PD_PREC_F32 1  /* fp32 MFMA (v_mfma_f32_16x16x4_f32): bit-faithful fp32 arithmetic */
 #define PD_PREC_F16 2  /* fp16 MFMA operands (the reference's own GPU dtype, README.md:44-45 torch_dtype=torch.float16;
                           same MFMA rate as bf16, 3 more mantissa bits), fp32 accumulate / norm statistics / softmax */
-#define PD_PREC_F16X2 3 /* fp32 storage; every MFMA operand split into fp16 hi + lo in registers, two fp16 MFMAs per
-                           product (all four cross terms): ~22-bit operands, fp32-class results at 4x the fp32 MFMA rate */
+#define PD_PREC_F16X2 3 /* fp32 storage; every MFMA operand split into fp16 hi + lo in registers, three fp16 MFMAs per
+                           8 K-elements (hi*hi + hi*lo + lo*hi): ~22-bit operands, fp32-class results at ~5x the fp32 MFMA rate */
 
 /* where caller-owned I/O buffers live */
 #define PD_MEM_HOST 0

@@ -238,6 +238,23 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         // registers for the whole kernel and spill the accumulators)
         int frv = fr;
         asm volatile("" : "+v"(frv));
+        if constexpr (P == PREC_F16X2) {   // both half-steps at once: 3 MFMAs per accumulator and unit (pd_mma.h)
+            FragX2 af[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int py = wm * 4 + m;
+                const int prow = (((y0 - 1 + py + ky) >> UPS) - sy0) * PW + (((x0 - 1 + frv + kx) >> UPS) - sx0);
+                af[m] = prep_x2(*reinterpret_cast<const uint4*>(pa + swzp(prow, fq)), *reinterpret_cast<const uint4*>(pa + swzp(prow, 4 + fq)));
+            }
+            const char* w0 = wa + swzp(wn * 80 + frv, fq);
+            const char* w1 = wa + swzp(wn * 80 + frv, 4 + fq);
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                const FragX2 wf = prep_x2(*reinterpret_cast<const uint4*>(w0 + n * 16 * ROWB), *reinterpret_cast<const uint4*>(w1 + n * 16 * ROWB));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) mma_x2(wf, af[m], acc[n][m]);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             typename Frag<P>::A af[4];

@@ -233,6 +233,22 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const char* sa = smem + buf * (BM + BN) * BKB;
         const char* sb = sa + BM * BKB;
+        if constexpr (P == PREC_F16X2) {   // both half-steps at once: 3 MFMAs per accumulator and K step (pd_mma.h)
+            FragX2 af[MT], wf[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                af[m] = prep_x2(*reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, fq)),
+                                *reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, 4 + fq)));
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                wf[n] = prep_x2(*reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, fq)),
+                                *reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, 4 + fq)));
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mma_x2(wf[n], af[m], acc[n][m]);
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             typename Frag<P>::A af[MT];

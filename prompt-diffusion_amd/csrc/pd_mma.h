@@ -72,6 +72,22 @@ __device__ __forceinline__ void mma(const typename Frag<P>::W& w, const typename
                                                       acc, 0, 0, 0);
     }
 }
+// PREC_F16X2 over a whole K step (two 16-byte fp32 fragments per operand = 8 K elements): hi / lo planes of 8 halfs each and
+// THREE MFMAs per accumulator -- wh*ah + wh*al + wl*ah; the dropped lo*lo term is 2^-22 of the product -- instead of the four
+// that two independent half-steps issue.
+struct FragX2 { uint4 hi, lo; };
+__device__ __forceinline__ FragX2 prep_x2(const uint4& f0, const uint4& f1) {
+    FragX2 r;
+    split_f16(f0, r.hi.x, r.hi.y, r.lo.x, r.lo.y);
+    split_f16(f1, r.hi.z, r.hi.w, r.lo.z, r.lo.w);
+    return r;
+}
+__device__ __forceinline__ void mma_x2(const FragX2& w, const FragX2& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w.hi), __builtin_bit_cast(f16x8, a.hi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w.hi), __builtin_bit_cast(f16x8, a.lo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w.lo), __builtin_bit_cast(f16x8, a.hi), acc, 0, 0, 0);
+}
+
 // the same from two raw 16-byte fragments (converts per call in PREC_F16X2: attention only)
 template <int P>
 __device__ __forceinline__ void mma_raw(const uint4& w, const uint4& a, f32x4& acc) {
