@@ -228,6 +228,58 @@ int pd_text_weights_missing(pd_engine* e);
 /* Same for one Linear / conv1x1 layer ([M,K] x [N,K]^T, optional residual add) in isolation. */
 int pd_bench_linear(pd_engine* e, int32_t M, int32_t K, int32_t N, int32_t residual, int32_t iters, float* ms);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * SD3 / MMDiT variant of the path.  Replaces, per denoising step,
+ *     SD3PromptDiffusionModel.forward                       promptdiffusioncontrolnet_sd3.py:362-483
+ *     self.transformer(..., block_controlnet_hidden_states)  promptdiffusioncontrolnetpipeline_sd3.py:1226-1234
+ *     CFG + scheduler.step (FlowMatchEuler)                  promptdiffusioncontrolnetpipeline_sd3.py:1237-1243
+ * The block arithmetic lives in diffusers (absent offline): PARITY UNPINNED, checked against oracle/sd3_oracle.py only.
+ * Parameter names are diffusers' state-dict names under the prefixes "transformer." (SD3Transformer2DModel) and
+ * "controlnet." (SD3PromptDiffusionModel).  The example-pair / query conditions arrive as VAE latents: down_proj and
+ * vae.encode (encode_support_pair, promptdiffusioncontrolnet_sd3.py:189-198) stay with the caller.
+ * Not built: qk_norm, dual_attention_layers (SD3.5), joint_attention_kwargs / LoRA scale. */
+typedef struct pd_sd3_config {
+    int32_t in_channels;        /* 16 */
+    int32_t out_channels;       /* 16 */
+    int32_t patch_size;         /* 2 */
+    int32_t heads;              /* 24 (SD3-medium); hidden = heads * head_dim */
+    int32_t head_dim;           /* 64 */
+    int32_t layers;             /* transformer blocks (24); the last one is context_pre_only */
+    int32_t cn_layers;          /* ControlNet blocks (reference default 18, promptdiffusioncontrolnet_sd3.py:59); 0: no ControlNet */
+    int32_t joint_dim;          /* joint_attention_dim 4096 */
+    int32_t pooled_dim;         /* pooled_projection_dim 2048 */
+    int32_t pos_embed_max_size; /* 192: side of the transformer's sin/cos table "transformer.pos_embed.pos_embed" */
+    int32_t cn_pos_embed_max_size; /* the ControlNet's own table (promptdiffusioncontrolnet_sd3.py:102 default 96); 0: same */
+    int32_t reserved[5];
+} pd_sd3_config;
+
+typedef struct pd_sd3_args {
+    int32_t batch;            /* B: rows of every tensor below */
+    int32_t height, width;    /* latent size (multiples of patch_size) */
+    int32_t context_len;      /* S tokens of `context` */
+    int32_t mem;              /* PD_MEM_HOST / PD_MEM_DEVICE of all tensor pointers (timestep is always host) */
+    float conditioning_scale; /* controlnet_conditioning_scale */
+    const float* latents;     /* [B, C, H, W] */
+    const float* timestep;    /* [B] (sigma * 1000), host */
+    const float* context;     /* [B, S, joint_dim]  encoder_hidden_states */
+    const float* pooled;      /* [B, pooled_dim]    pooled_projections */
+    const float* cond;        /* [B, C, H, W] controlnet_cond latents, or NULL: transformer alone */
+    const float* pair;        /* [B, C, H, W] controlnet_example_pair_cond latents */
+    int64_t reserved[4];
+} pd_sd3_args;
+
+/* Registers the SD3 networks' parameters on an existing engine (any pd_config; the UNet path keeps working) and allocates
+ * their weights.  Once per engine. */
+int pd_sd3_configure(pd_engine* e, const pd_sd3_config* cfg);
+int pd_sd3_weights_missing(pd_engine* e);
+/* One evaluation: velocity [B, out_channels, H, W] (fp32, args->mem) = transformer(latents | ControlNet residuals). */
+int pd_sd3_forward(pd_engine* e, const pd_sd3_args* args, float* v_out);
+/* ControlNet alone: residual i as [B, (H/p)(W/p), hidden] fp32, i in [0, cn_layers) (controlnet_block_samples). */
+int pd_sd3_control(pd_engine* e, const pd_sd3_args* args, int32_t index, float* out);
+/* The whole loop: sigmas[steps + 1] (host, descending, last = 0 for a full schedule); guidance > 1 runs the doubled batch
+ * [negative ; positive]: context / pooled then hold 2B rows, latents / cond / pair B rows.  latents_out: [B, C, H, W]. */
+int pd_sd3_sample(pd_engine* e, const pd_sd3_args* args, const float* sigmas, int32_t steps, float guidance, float* latents_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,203 @@
+"""CPU restatement (NumPy fp32) of the SD3 hot path of the reference: SD3PromptDiffusionModel.forward
+(/root/reference/promptdiffusioncontrolnet_sd3.py:362-483) + the MMDiT it steers + the flow-matching Euler loop of
+promptdiffusioncontrolnetpipeline_sd3.py:1192-1245.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED.  The block arithmetic (SD3Transformer2DModel, JointTransformerBlock, AdaLayerNormZero / Continuous,
+PatchEmbed, CombinedTimestepTextProjEmbeddings, FlowMatchEulerDiscreteScheduler) lives in diffusers >= 0.33.0.dev0, which is
+neither vendored in the reference tree nor installed here, and no SD3 weights or fixtures exist offline.  What follows
+restates the published MMDiT (Esser et al. 2024, "Scaling Rectified Flow Transformers for High-Resolution Image Synthesis",
+Fig. 2 / Sec. 4) under the reference's own call sites and parameter names:
+  * controlnet forward  promptdiffusioncontrolnet_sd3.py:431-476: pos_embed(latents) + pos_embed_input(cond) +
+    pos_embed_input(example pair), joint blocks, one zero Linear per block, * conditioning_scale
+  * transformer forward consumed as self.transformer(hidden_states, timestep, encoder_hidden_states, pooled_projections,
+    block_controlnet_hidden_states) (pipeline :1226-1234); residual i is added after block i with
+    interval = ceil(len(blocks) / len(residuals))
+  * CFG uncond + s (text - uncond) (:1237-1239) and latents + (sigma_next - sigma) * v (scheduler.step, :1243)
+The engine path (csrc/sd3.cpp) is tested against THIS file only (tests/test_sd3_gpu.py)."""
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+
+def linear(x, w, b=None):
+    y = x @ w.T
+    return y if b is None else y + b
+
+
+def silu(x):
+    return x / (1.0 + np.exp(-x))
+
+
+def gelu_tanh(x):
+    return (0.5 * x * (1.0 + np.tanh(F32(math.sqrt(2.0 / math.pi)) * (x + F32(0.044715) * x * x * x)))).astype(F32)
+
+
+def layer_norm_noaffine(x, eps=1e-6):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return ((x - mu) / np.sqrt(var + F32(eps))).astype(F32)
+
+
+def timestep_embedding(t, dim=256, max_period=10000.0):
+    """Timesteps(num_channels=256, flip_sin_to_cos=True, downscale_freq_shift=0): [cos, sin]."""
+    half = dim // 2
+    freqs = np.exp(-math.log(max_period) * np.arange(half, dtype=F32) / F32(half)).astype(F32)
+    a = np.asarray(t, F32)[:, None] * freqs[None]
+    return np.concatenate([np.cos(a), np.sin(a)], axis=-1).astype(F32)
+
+
+def sincos_pos_embed(dim, grid, base_size, interpolation_scale=1.0):
+    """2-D sin/cos table [grid*grid, dim] (get_2d_sincos_pos_embed: w-axis first half, h-axis second half)."""
+    def one(pos, d):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        out = pos.reshape(-1)[:, None] * omega[None]
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    gh = np.arange(grid, dtype=np.float64) / (grid / base_size) / interpolation_scale
+    gw = np.arange(grid, dtype=np.float64) / (grid / base_size) / interpolation_scale
+    mw, mh = np.meshgrid(gw, gh)             # w varies fastest
+    return np.concatenate([one(mw, dim // 2), one(mh, dim // 2)], axis=1).astype(F32)
+
+
+def cropped_pos_embed(table, max_size, h, w):
+    """PatchEmbed.cropped_pos_embed: centre crop of the [max, max, D] table to [h, w]."""
+    D = table.shape[-1]
+    t = table.reshape(max_size, max_size, D)
+    top, left = (max_size - h) // 2, (max_size - w) // 2
+    return t[top:top + h, left:left + w].reshape(h * w, D)
+
+
+def patch_embed(x, w, b, p=2):
+    """Conv2d(C, D, kernel p, stride p) then flatten(2).transpose(1, 2): [B, C, H, W] -> [B, (H/p)(W/p), D]."""
+    B, C, H, W = x.shape
+    xr = x.reshape(B, C, H // p, p, W // p, p).transpose(0, 2, 4, 1, 3, 5).reshape(B, (H // p) * (W // p), C * p * p)
+    return linear(xr, w.reshape(w.shape[0], -1), b).astype(F32)
+
+
+def attention(q, k, v, heads):
+    B, Nq, D = q.shape
+    dh = D // heads
+    sp = lambda t: t.reshape(B, t.shape[1], heads, dh).transpose(0, 2, 1, 3)
+    s = np.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * F32(dh ** -0.5)
+    s = s - s.max(-1, keepdims=True)
+    e = np.exp(s)
+    a = e / e.sum(-1, keepdims=True)
+    return np.einsum("bhij,bhjd->bhid", a, sp(v)).transpose(0, 2, 1, 3).reshape(B, Nq, D).astype(F32)
+
+
+def joint_block(sd, pre, cfg, x, c, temb, context_pre_only):
+    """JointTransformerBlock: AdaLN-Zero on both streams, attention over [image ; context] tokens, gated residuals."""
+    P = lambda n: sd[pre + n]
+    e = silu(temb)
+    m = linear(e, P("norm1.linear.weight"), P("norm1.linear.bias"))
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = np.split(m, 6, axis=-1)
+    xn = layer_norm_noaffine(x) * (1 + sc_a[:, None]) + sh_a[:, None]
+    mc = linear(e, P("norm1_context.linear.weight"), P("norm1_context.linear.bias"))
+    if context_pre_only:      # AdaLayerNormContinuous: chunk order (scale, shift)
+        c_sc, c_sh = np.split(mc, 2, axis=-1)
+        cn = layer_norm_noaffine(c) * (1 + c_sc[:, None]) + c_sh[:, None]
+    else:
+        c_sh_a, c_sc_a, c_g_a, c_sh_m, c_sc_m, c_g_m = np.split(mc, 6, axis=-1)
+        cn = layer_norm_noaffine(c) * (1 + c_sc_a[:, None]) + c_sh_a[:, None]
+    N = x.shape[1]
+    q = np.concatenate([linear(xn, P("attn.to_q.weight"), P("attn.to_q.bias")),
+                        linear(cn, P("attn.add_q_proj.weight"), P("attn.add_q_proj.bias"))], axis=1)
+    k = np.concatenate([linear(xn, P("attn.to_k.weight"), P("attn.to_k.bias")),
+                        linear(cn, P("attn.add_k_proj.weight"), P("attn.add_k_proj.bias"))], axis=1)
+    v = np.concatenate([linear(xn, P("attn.to_v.weight"), P("attn.to_v.bias")),
+                        linear(cn, P("attn.add_v_proj.weight"), P("attn.add_v_proj.bias"))], axis=1)
+    o = attention(q, k, v, cfg.heads)
+    ox = linear(o[:, :N], P("attn.to_out.0.weight"), P("attn.to_out.0.bias"))
+    x = x + g_a[:, None] * ox
+    xn2 = layer_norm_noaffine(x) * (1 + sc_m[:, None]) + sh_m[:, None]
+    ff = linear(gelu_tanh(linear(xn2, P("ff.net.0.proj.weight"), P("ff.net.0.proj.bias"))), P("ff.net.2.weight"), P("ff.net.2.bias"))
+    x = (x + g_m[:, None] * ff).astype(F32)
+    if context_pre_only:
+        return None, x
+    oc = linear(o[:, N:], P("attn.to_add_out.weight"), P("attn.to_add_out.bias"))
+    c = c + c_g_a[:, None] * oc
+    cn2 = layer_norm_noaffine(c) * (1 + c_sc_m[:, None]) + c_sh_m[:, None]
+    ffc = linear(gelu_tanh(linear(cn2, P("ff_context.net.0.proj.weight"), P("ff_context.net.0.proj.bias"))),
+                 P("ff_context.net.2.weight"), P("ff_context.net.2.bias"))
+    c = (c + c_g_m[:, None] * ffc).astype(F32)
+    return c, x
+
+
+def time_text_embed(sd, pre, t, pooled):
+    """CombinedTimestepTextProjEmbeddings: MLP(sinusoid(t)) + MLP(pooled)."""
+    P = lambda n: sd[pre + n]
+    te = linear(silu(linear(timestep_embedding(t), P("timestep_embedder.linear_1.weight"), P("timestep_embedder.linear_1.bias"))),
+                P("timestep_embedder.linear_2.weight"), P("timestep_embedder.linear_2.bias"))
+    pe = linear(silu(linear(pooled, P("text_embedder.linear_1.weight"), P("text_embedder.linear_1.bias"))),
+                P("text_embedder.linear_2.weight"), P("text_embedder.linear_2.bias"))
+    return (te + pe).astype(F32)
+
+
+def controlnet_forward(sd, cfg, x, t, ctx, pooled, cond, pair, scale=1.0, prefix="controlnet."):
+    """SD3PromptDiffusionModel.forward (promptdiffusioncontrolnet_sd3.py:431-476): list of cfg.cn_layers residuals."""
+    P = lambda n: sd[prefix + n]
+    B, C, H, W = x.shape
+    h, w = H // cfg.patch, W // cfg.patch
+    hs = patch_embed(x, P("pos_embed.proj.weight"), P("pos_embed.proj.bias"), cfg.patch)
+    hs = hs + cropped_pos_embed(P("pos_embed.pos_embed")[0], cfg.cn_pos_embed_max_size or cfg.pos_embed_max_size, h, w)[None]
+    temb = time_text_embed(sd, prefix + "time_text_embed.", t, pooled)
+    c = linear(ctx, P("context_embedder.weight"), P("context_embedder.bias"))
+    pi_w, pi_b = P("pos_embed_input.proj.weight"), P("pos_embed_input.proj.bias")
+    hs = (hs + patch_embed(cond, pi_w, pi_b, cfg.patch) + patch_embed(pair, pi_w, pi_b, cfg.patch)).astype(F32)   # :440
+    res = []
+    for i in range(cfg.cn_layers):
+        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, False)
+        res.append(hs)
+    return [(linear(r, P(f"controlnet_blocks.{i}.weight"), P(f"controlnet_blocks.{i}.bias")) * F32(scale)).astype(F32)
+            for i, r in enumerate(res)]
+
+
+def transformer_forward(sd, cfg, x, t, ctx, pooled, control=None, prefix="transformer."):
+    """SD3Transformer2DModel.forward as the pipeline calls it (:1226-1234): velocity [B, C, H, W]."""
+    P = lambda n: sd[prefix + n]
+    B, C, H, W = x.shape
+    h, w = H // cfg.patch, W // cfg.patch
+    hs = patch_embed(x, P("pos_embed.proj.weight"), P("pos_embed.proj.bias"), cfg.patch)
+    hs = (hs + cropped_pos_embed(P("pos_embed.pos_embed")[0], cfg.pos_embed_max_size, h, w)[None]).astype(F32)
+    temb = time_text_embed(sd, prefix + "time_text_embed.", t, pooled)
+    c = linear(ctx, P("context_embedder.weight"), P("context_embedder.bias"))
+    interval = int(math.ceil(cfg.layers / len(control))) if control else 0
+    for i in range(cfg.layers):
+        last = i == cfg.layers - 1
+        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, last)
+        if control and not last:
+            hs = (hs + control[i // interval]).astype(F32)
+    m = linear(silu(temb), P("norm_out.linear.weight"), P("norm_out.linear.bias"))
+    sc, sh = np.split(m, 2, axis=-1)
+    hs = layer_norm_noaffine(hs) * (1 + sc[:, None]) + sh[:, None]
+    out = linear(hs, P("proj_out.weight"), P("proj_out.bias"))            # [B, h*w, p*p*Cout]
+    p, Co = cfg.patch, cfg.out_channels
+    out = out.reshape(B, h, w, p, p, Co).transpose(0, 5, 1, 3, 2, 4).reshape(B, Co, h * p, w * p)   # nhwpqc -> nchpwq
+    return out.astype(F32)
+
+
+def flow_match_sigmas(steps, shift=3.0, num_train=1000):
+    """FlowMatchEulerDiscreteScheduler.set_timesteps: sigmas from sigma_max to sigma_min, shifted, then 0."""
+    smax, smin = 1.0, 1.0 / num_train
+    shifted = lambda s: shift * s / (1 + (shift - 1) * s)
+    ts = np.linspace(shifted(smax) * num_train, shifted(smin) * num_train, steps)
+    s = ts / num_train
+    s = shifted(s)
+    return np.concatenate([s, [0.0]]).astype(F32)
+
+
+def sample(sd, cfg, latents, ctx, ctx_neg, pooled, pooled_neg, cond, pair, steps, guidance, scale=1.0, shift=3.0):
+    """pipeline :1192-1245: CFG-doubled batch ([negative, positive]), ControlNet then transformer, Euler step."""
+    sig = flow_match_sigmas(steps, shift)
+    x = latents
+    B = x.shape[0]
+    for i in range(steps):
+        t = np.full((2 * B,), sig[i] * 1000.0, F32)
+        xi = np.concatenate([x, x])
+        cc, pp = np.concatenate([ctx_neg, ctx]), np.concatenate([pooled_neg, pooled])
+        ctl = controlnet_forward(sd, cfg, xi, t, cc, pp, np.concatenate([cond, cond]), np.concatenate([pair, pair]), scale)
+        v = transformer_forward(sd, cfg, xi, t, cc, pp, ctl)
+        v = v[:B] + F32(guidance) * (v[B:] - v[:B])
+        x = (x + (sig[i + 1] - sig[i]) * v).astype(F32)
+    return x

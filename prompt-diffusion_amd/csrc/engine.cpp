@@ -502,7 +502,9 @@ int pd_engine::init_random(uint64_t seed) {
         ++k;
         const uint64_t sd = seed * 0x9E3779B97F4A7C15ull + k;
         if (p.kind == 0) {
-            long long n = p.geglu_vec ? ((p.geglu_half + 79) / 80) * 160 : p.shape[0];
+            long long n = 1;
+            for (int64_t d : p.shape) n *= d;
+            if (p.geglu_vec) n = ((p.geglu_half + 79) / 80) * 160;
             float scale = 0.02f, shift = 0.f;
             if (p.init == 'g') { scale = 0.1f; shift = 1.f; }
             if (p.init == 'e') scale = 0.1f;
@@ -612,6 +614,9 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.slab = nullptr;
     p.gn_coef = gn_coef;
     p.gn_silu = gn_silu ? 1 : 0;
+    p.gate = gx.gate; p.gate_stride = gx.gate_stride;
+    p.c_sample_rows = gx.c_sample_rows; p.c_row_off = gx.c_row_off; p.vt_tok_off = gx.vt_tok_off;
+    gx = GemmExtra{};
     if (ln_in) {   // LayerNorm of `in` folded into this layer: raw A, folded weights, statistics from the producer
         if (!m.w_ln) { pd_set_error("internal: folded LayerNorm weights missing"); return 1; }
         p.W = m.w_ln;
@@ -816,15 +821,15 @@ int pd_engine::layernorm(const Act& x, Act& y, const float* g, const float* b) {
 }
 
 int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B,
-                         int Nq, int Nk, int C, int heads, bool causal) {
+                         int Nq, int Nk, int C, int heads, bool causal, long long q_bs, long long k_bs) {
     if (heads <= 0) heads = cfg.num_heads;
     if (arena.dry) return 0;
     PD_TRY(check_arena());
     AttnParams p{};
     p.Q = Q; p.K = K; p.VT = VT; p.O = O;
     p.ldq = ldq; p.ldk = ldk; p.ldo = ldo; p.vt_ld = vt_ld;
-    p.q_bs = (long long)Nq * ldq;
-    p.k_bs = (long long)Nk * ldk;
+    p.q_bs = q_bs ? q_bs : (long long)Nq * ldq;   // explicit strides: queries / keys that are row ranges of a larger buffer
+    p.k_bs = k_bs ? k_bs : (long long)Nk * ldk;
     p.vt_bs = (long long)C * vt_ld;
     p.o_bs = (long long)Nq * ldo;
     p.Nq = Nq; p.Nk = Nk; p.heads = heads; p.dh = C / heads;

@@ -139,6 +139,24 @@ struct TextW {
     float *fln_g = nullptr, *fln_b = nullptr;
 };
 
+// SD3 / MMDiT: one JointTransformerBlock
+struct Sd3BlockW {
+    WMat qkv, qkv_c;     // to_q|to_k|to_v and add_q_proj|add_k_proj|add_v_proj, rows [0,D) q, [D,2D) k, [2D,3D) v
+    WMat out, out_c;     // attn.to_out.0, attn.to_add_out (absent when pre_only)
+    WMat ff1, ff2, ffc1, ffc2;
+    int mod_off = 0, mod_c_off = 0;   // first row of norm1.linear / norm1_context.linear in the net's modulation matrix
+    bool pre_only = false;            // context_pre_only (last transformer block): context gives keys / values only
+};
+struct Sd3NetW {
+    bool built = false;
+    int layers = 0, pos_max = 0;
+    WMat pe, pe_in, t1, t2, p1, p2, ctx_emb, mod, proj_out;
+    float* pos = nullptr;             // pos_embed.pos_embed [pos_max * pos_max][D] fp32
+    std::vector<Sd3BlockW> blocks;
+    std::vector<WMat> zero;           // controlnet_blocks
+    int mod_rows = 0, norm_out_off = 0;
+};
+
 struct Param {
     std::string name;
     std::vector<int64_t> shape;
@@ -153,7 +171,7 @@ struct Param {
     bool conv = false;  // OIHW source
     char init = 'w';    // recipe class for pd_init_random_weights: w, b, g(amma), e(beta)
     bool loaded = false;
-    int group = 0;      // 0: UNet + ControlNet (needed to sample), 1: VAE decoder, 2: text transformer
+    int group = 0;      // 0: UNet + ControlNet (needed to sample), 1: VAE decoder, 2: text transformer, 3: SD3 networks
 };
 
 struct Act {
@@ -299,6 +317,22 @@ struct pd_engine {
     int vae_forward(const float* latents_dev, int B, int h, int w, float* out_dev);
     int vae_attention(const Act& x, Act& out);
 
+    // SD3 / MMDiT path (sd3.cpp)
+    pd_sd3_config sd3{};
+    Sd3NetW sd3_tr, sd3_cn;
+    struct Sd3Io {   // device pointers of one evaluation
+        const float *latents, *context, *pooled, *cond, *pair;
+        const float* t_host;
+        int B, H, W, S;
+        float scale;
+    };
+    void build_sd3_net(const std::string& prefix, Sd3NetW& net, bool controlnet);
+    int sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs, Act& c, Act& modbuf);
+    int sd3_block(Sd3NetW& net, const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, int heads);
+    int sd3_forward(const Sd3Io& io, float* v_out_dev, int control_index, float* control_out_dev);
+    // one-shot extras of the next gemm() call (MMDiT: gated residual, joint-buffer row remap)
+    struct GemmExtra { const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0; } gx;
+
     // weights
     int load(const char* name, const void* data, const int64_t* shape, int ndim, int dtype);
     int init_random(uint64_t seed);
@@ -323,7 +357,7 @@ struct pd_engine {
     int resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride);
     int transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv);
     int attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B, int Nq,
-                  int Nk, int C, int heads = 0, bool causal = false);
+                  int Nk, int C, int heads = 0, bool causal = false, long long q_bs = 0, long long k_bs = 0);
 
     // networks
     int run_controlnet(const Act& x_in, int emb_row, int emb_stride, const float* scales);

@@ -38,7 +38,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row * BKB) + ((
 // P: compute type (DT_F32: fp32 MFMA mode; DT_BF16 / DT_F16: 2-byte operands).  CONV: 3x3 gather (else rows of A
 // are contiguous).  AF32: 2-byte compute with an fp32 A source (converted while staging; only meaningful when P != DT_F32).
 // GG: the GEGLU epilogue (act == 2) instead of the plain one -- a wave's WTN columns are whole [80 x | 80 gate] blocks.
-template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32, bool GG = false>
+// MM: the MMDiT epilogue extras (pd_mma.h epilogue4<true>), linear layers of the SD3 path only.
+template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32, bool GG = false, bool MM = false>
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) void igemm_kernel(GemmParams p) {
     constexpr bool F32 = prec_f32_storage(P);
     // register prefetch depth: two K steps ahead (two named staging sets) unless the fp32->bf16 staging
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
         for (int n = 0; n < NT; ++n) {
             const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
             if (gn >= p.N) continue;
-            const f32x4 v = epilogue4(p, gm, gn, sample, tok, acc[n][m], ln_mean, ln_rstd);
+            const f32x4 v = epilogue4<MM>(p, gm, gn, sample, tok, acc[n][m], ln_mean, ln_rstd);
             if constexpr (LNF) {
                 if (p.stats_out) {
                     rs += (v[0] + v[1]) + (v[2] + v[3]);
@@ -444,16 +445,16 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
         const int sample = gm / p.rows_per_sample;
         float ln_mean = 0.f, ln_rstd = 0.f;
         if (p.ln_stats) ln_row_stats(p, gm, ln_mean, ln_rstd);
-        epilogue4(p, gm, gn, sample, gm - sample * p.rows_per_sample, v, ln_mean, ln_rstd);
+        epilogue4<true>(p, gm, gn, sample, gm - sample * p.rows_per_sample, v, ln_mean, ln_rstd);
     }
 }
 
-template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32, bool GG = false>
+template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32, bool GG = false, bool MM = false>
 int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB + BM * 8;   // staging buffers + {mean, rstd} of the block's rows
     static unsigned long long attr_done = 0;
-    auto kfn = igemm_kernel<P, BM, BN, WM, WN, CONV, AF32, GG>;
+    auto kfn = igemm_kernel<P, BM, BN, WM, WN, CONV, AF32, GG, MM>;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM_BYTES, &attr_done)) return 1;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
     dim3 grid(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1);
@@ -498,6 +499,18 @@ int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
         if (tile == 3) return launch_one<P, 256, 320, 4, 2, false, false, true>(p, s, mid);
         if (tile == 1) return launch_one<P, 256, 160, 8, 1, false, false, true>(p, s, mid);
         return launch_one<P, 128, 160, 4, 1, false, false, true>(p, s, mid);
+    }
+    if (p.act == 4 || p.gate || p.c_sample_rows) {   // MMDiT epilogue extras: linear layers over operands of the compute type
+        if (conv || af32) return 1;
+        if constexpr (F) {
+            if (tile == 1 || tile == 3) return launch_one<P, 256, 160, 4, 2, false, false, false, true>(p, s, mid);
+            return launch_one<P, 128, 160, 2, 2, false, false, false, true>(p, s, mid);
+        } else {
+            // (the 256 x 320 tile spills 896 B per lane with the extras compiled in: its launches take the 256 x 160 tile)
+            if (tile == 2) return launch_one<P, 128, 160, 4, 2, false, false, false, true>(p, s, mid);
+            if (tile == 1 || tile == 3) return launch_one<P, 256, 160, 4, 2, false, false, false, true>(p, s, mid);
+            return launch_one<P, 128, 160, 2, 2, false, false, false, true>(p, s, mid);
+        }
     }
     if constexpr (F) {   // fp32 mode: the 128x160 / 256x160 four-wave-group tiles only
         if (tile == 1 || tile == 3) return conv ? launch_one<P, 256, 160, 4, 2, true, false>(p, s, mid) : launch_one<P, 256, 160, 4, 2, false, false>(p, s, mid);

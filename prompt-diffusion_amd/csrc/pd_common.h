@@ -158,7 +158,7 @@ struct GemmParams {
     int Hin, Win, Hout, Wout, stride, ups;  // conv geometry; ups=1: nearest x2 upsample fused in the gather
     int rows_per_sample;  // Hout*Wout (conv) or tokens per sample (linear)
     int rowvec_stride;    // elements between samples in rowvec (0: one row for all)
-    int act;              // 0 none, 1 SiLU, 2 GEGLU (weights pre-interleaved in 80+80 blocks)
+    int act;              // 0 none, 1 SiLU, 2 GEGLU (weights pre-interleaved in 80+80 blocks), 3 quick-GELU, 4 tanh-GELU
     int a_silu;           // apply SiLU to A on load (emb_layers)
     float out_scale;      // applied to (acc + bias [+ rowvec]) before the residual
     int vt_begin, vt_ld;  // see VT
@@ -182,6 +182,12 @@ struct GemmParams {
     // one wave) leaves its {sum, sum of squares} in stats_out[M][stats_parts][2] (igemm_kernel epilogue only)
     float* stats_out;
     int stats_parts;
+    // MMDiT (sd3.cpp): per-sample gate row multiplied into (acc + bias) * out_scale before the residual (AdaLN-Zero), and a
+    // row remap of the stores so that two token streams land in one joint [sample][c_sample_rows] buffer:
+    // row = sample * c_sample_rows + c_row_off + tok (c_sample_rows = 0: row = gm); V^T tokens shift by vt_tok_off.
+    const float* gate;
+    int gate_stride;
+    int c_sample_rows, c_row_off, vt_tok_off;
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
@@ -236,4 +242,11 @@ int launch_cfg_ddim(const void* eps, int eps_dt, int eps_C, float* x_state, floa
                     void* x_in, const float* noise, int B, int HW, int C, int Cpad, int use_cfg, DdimCoef k,
                     float temperature, int do_update, hipStream_t s);
 int launch_fill_random(void* p, int dt, long long n, float scale, float shift, uint64_t seed, hipStream_t s);
+// sd3_kernels.hip: element-wise pieces of the MMDiT path
+int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, int mod_stride, int shift_off, int scale_off, int rows,
+                 int rows_per_sample, int C, float eps, hipStream_t s);
+int launch_patchify(const float* nchw, void* out, int out_dt, int B, int C, int H, int W, int patch, int Cpad, int Kpad, hipStream_t s);
+int launch_pos_crop(const float* table, float* out, int B, int h, int w, int max_size, int D, hipStream_t s);
+int launch_unpatchify(const void* in, int in_dt, int ld, float* nchw, int B, int C, int h, int w, int patch, hipStream_t s);
+int launch_cfg_euler(const float* v, float* x, int B, long long n, float guidance, float dsigma, int use_cfg, hipStream_t s);
 int launch_fill_x_in(const float* x_state_nchw, float* x_in, int B, int dup, int C, int Cpad, int HW, hipStream_t s);

@@ -133,7 +133,10 @@ __device__ __forceinline__ f32x4 ln_apply4(const GemmParams& p, int gn, f32x4 v,
 }
 
 // (folded LayerNorm) / bias / time-embedding row / activation / scale / residual / (transposed) store of 4 consecutive
-// channels; returns the value stored (before rounding to the output type)
+// channels; returns the value stored (before rounding to the output type).  MM: the MMDiT extras (tanh-GELU, per-sample gate,
+// joint-buffer row remap) -- compile-time, because even as untaken branches they push the 256 x 320 tile and the
+// wave-specialised patch conv (both at the VGPR cap) into scratch.
+template <bool MM = false>
 __device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, int sample, int tok, f32x4 v, float ln_mean = 0.f,
                                            float ln_rstd = 0.f) {
     if (p.ln_stats) v = ln_apply4(p, gn, v, ln_mean, ln_rstd);
@@ -146,11 +149,24 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + __expf(-1.702f * v[j]));
     }
+    if constexpr (MM) {
+        if (p.act == 4) {   // tanh-GELU (MMDiT feed-forward): 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u))
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = 0.7978845608028654f * fmaf(0.044715f * v[j] * v[j], v[j], v[j]);
+                v[j] = v[j] / (1.0f + __expf(-2.0f * u));
+            }
+        }
+    }
     v *= p.out_scale;
+    if constexpr (MM) {
+        if (p.gate) v *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)sample * p.gate_stride + gn);
+    }
     if (p.R) v += load4(p.R, (size_t)gm * p.ldr + gn, p.r_dt);
     if (gn >= p.vt_begin) {
         // transposed store (attention V^T): [sample][channel][token]
-        const size_t base = ((size_t)sample * (p.N - p.vt_begin) + (gn - p.vt_begin)) * p.vt_ld + tok;
+        size_t base = ((size_t)sample * (p.N - p.vt_begin) + (gn - p.vt_begin)) * p.vt_ld + tok;
+        if constexpr (MM) base += p.vt_tok_off;
         if (p.c_dt == DT_F32) {
             float* o = reinterpret_cast<float*>(p.VT);
 #pragma unroll
@@ -161,7 +177,11 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, 
             for (int j = 0; j < 4; ++j) o[base + (size_t)j * p.vt_ld] = cvt16_rt(v[j], p.c_dt);
         }
     } else {
-        store4(p.C, (size_t)gm * p.ldc + gn, p.c_dt, v);
+        size_t crow = (size_t)gm;
+        if constexpr (MM) {
+            if (p.c_sample_rows) crow = (size_t)sample * p.c_sample_rows + p.c_row_off + tok;
+        }
+        store4(p.C, crow * p.ldc + gn, p.c_dt, v);
     }
     return v;
 }

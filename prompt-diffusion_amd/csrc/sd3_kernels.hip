@@ -1,0 +1,165 @@
+// pdengine: element-wise kernels of the SD3 / MMDiT path (SURVEY.md §8f "next" row N4; host side in sd3.cpp).
+// All HBM-bound single passes; the contractions run on the igemm / attention kernels of the UNet path.
+#include "pd_common.h"
+
+// AdaLayerNormZero / AdaLayerNormContinuous body: y = LN(x) (no affine, eps) * (1 + scale[b]) + shift[b].
+// One wave per row, the row held in registers between the two passes; C <= 2048, C % 4 == 0.
+// mod: fp32 [B][mod_stride] (output of the modulation GEMM), the chunk of this norm at shift_off / scale_off.
+template <int XD, int YD>
+__global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ mod,
+                                                     int mod_stride, int shift_off, int scale_off, int rows, int rows_per_sample,
+                                                     int C, float eps) {
+    constexpr int MAXV = 8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = C >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        v[k] = vi < nv ? load4(x, (size_t)row * C + (size_t)vi * 4, XD) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        if (lane + 64 * k < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[k][j] - mean; q = fmaf(d, d, q); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    const float* mrow = mod + (size_t)(row / rows_per_sample) * mod_stride;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nv) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(mrow + scale_off + vi * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(mrow + shift_off + vi * 4);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf((v[k][j] - mean) * rstd, 1.0f + sc[j], sh[j]);
+            store4(y, (size_t)row * C + (size_t)vi * 4, YD, o);
+        }
+    }
+}
+
+int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, int mod_stride, int shift_off, int scale_off, int rows,
+                 int rows_per_sample, int C, float eps, hipStream_t s) {
+    if (C % 4 || C > 2048 || rows < 1 || rows_per_sample < 1 || (mod_stride | shift_off | scale_off) % 4) return 1;
+    const dim3 grid((rows + 3) / 4);
+#define PD_ADALN(XD, YD)                                                                                                       \
+    hipLaunchKernelGGL((adaln_kernel<XD, YD>), grid, dim3(256), 0, s, x, y, mod, mod_stride, shift_off, scale_off, rows, \
+                       rows_per_sample, C, eps)
+    if (x_dt == DT_F32 && y_dt == DT_F32) PD_ADALN(DT_F32, DT_F32);
+    else if (x_dt == DT_F32 && y_dt == DT_F16) PD_ADALN(DT_F32, DT_F16);
+    else if (x_dt == DT_F32 && y_dt == DT_BF16) PD_ADALN(DT_F32, DT_BF16);
+    else if (x_dt == DT_F16 && y_dt == DT_F16) PD_ADALN(DT_F16, DT_F16);
+    else if (x_dt == DT_BF16 && y_dt == DT_BF16) PD_ADALN(DT_BF16, DT_BF16);
+    else return 1;
+#undef PD_ADALN
+    return hipGetLastError() != hipSuccess;
+}
+
+// PatchEmbed's Conv2d(C, D, kernel = stride = patch) as a GEMM: rows [B * (H/p) * (W/p)][Kpad], k = (py * p + px) * Cpad + c
+// (the engine's tap-major conv weight layout, upload_rows), pad columns zero.
+template <int YD>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ in, void* __restrict__ out, int B, int C, int H, int W,
+                                                        int patch, int Cpad, int Kpad) {
+    const long long total = (long long)B * (H / patch) * (W / patch) * Kpad;
+    const int wq = W / patch, hq = H / patch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int k = (int)(i % Kpad);
+        const long long r = i / Kpad;
+        const int tap = k / Cpad, c = k - tap * Cpad;
+        float val = 0.f;
+        if (tap < patch * patch && c < C) {
+            const int px = tap % patch, py = tap / patch;
+            const int tx = (int)(r % wq), ty = (int)((r / wq) % hq), b = (int)(r / ((long long)wq * hq));
+            val = in[(((size_t)b * C + c) * H + (size_t)ty * patch + py) * W + (size_t)tx * patch + px];
+        }
+        if constexpr (YD == DT_F32) reinterpret_cast<float*>(out)[i] = val;
+        else reinterpret_cast<uint16_t*>(out)[i] = cvt16<YD>(val);
+    }
+}
+
+int launch_patchify(const float* nchw, void* out, int out_dt, int B, int C, int H, int W, int patch, int Cpad, int Kpad, hipStream_t s) {
+    if (patch < 1 || H % patch || W % patch || Cpad < C || Kpad < Cpad * patch * patch) return 1;
+    const long long total = (long long)B * (H / patch) * (W / patch) * Kpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (out_dt == DT_F32) hipLaunchKernelGGL((patchify_kernel<DT_F32>), dim3(blocks), dim3(256), 0, s, nchw, out, B, C, H, W, patch, Cpad, Kpad);
+    else if (out_dt == DT_F16) hipLaunchKernelGGL((patchify_kernel<DT_F16>), dim3(blocks), dim3(256), 0, s, nchw, out, B, C, H, W, patch, Cpad, Kpad);
+    else hipLaunchKernelGGL((patchify_kernel<DT_BF16>), dim3(blocks), dim3(256), 0, s, nchw, out, B, C, H, W, patch, Cpad, Kpad);
+    return hipGetLastError() != hipSuccess;
+}
+
+// PatchEmbed.cropped_pos_embed, broadcast over the batch: out[b][y * w + x][:] = table[(top + y) * max + left + x][:]
+__global__ __launch_bounds__(256) void pos_crop_kernel(const float* __restrict__ table, float* __restrict__ out, int B, int h, int w,
+                                                        int max_size, int D) {
+    const int top = (max_size - h) / 2, left = (max_size - w) / 2;
+    const int dv = D / 4;
+    const long long total = (long long)B * h * w * dv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int d = (int)(i % dv);
+        const long long r = i / dv;
+        const int x = (int)(r % w), y = (int)((r / w) % h);
+        const size_t src = ((size_t)(top + y) * max_size + left + x) * D + (size_t)d * 4;
+        *reinterpret_cast<f32x4*>(out + (size_t)r * D + (size_t)d * 4) = *reinterpret_cast<const f32x4*>(table + src);
+    }
+}
+
+int launch_pos_crop(const float* table, float* out, int B, int h, int w, int max_size, int D, hipStream_t s) {
+    if (h > max_size || w > max_size || D % 4 || B < 1) return 1;
+    const long long total = (long long)B * h * w * (D / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pos_crop_kernel, dim3(blocks), dim3(256), 0, s, table, out, B, h, w, max_size, D);
+    return hipGetLastError() != hipSuccess;
+}
+
+// proj_out rows [B * h * w][ld], column (py * p + px) * C + c  ->  fp32 NCHW [B, C, h p, w p]  ("nhwpqc->nchpwq")
+__global__ __launch_bounds__(256) void unpatchify_kernel(const void* __restrict__ in, int in_dt, int ld, float* __restrict__ out, int B,
+                                                          int C, int h, int w, int patch) {
+    const int H = h * patch, W = w * patch;
+    const long long total = (long long)B * C * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)((i / ((long long)W * H)) % C), b = (int)(i / ((long long)W * H * C));
+        const size_t row = ((size_t)b * h + y / patch) * w + x / patch;
+        const size_t col = (size_t)((y % patch) * patch + (x % patch)) * C + c;
+        out[i] = in_dt == DT_F32 ? reinterpret_cast<const float*>(in)[row * ld + col]
+                                 : cvt32_rt(reinterpret_cast<const uint16_t*>(in)[row * ld + col], in_dt);
+    }
+}
+
+int launch_unpatchify(const void* in, int in_dt, int ld, float* nchw, int B, int C, int h, int w, int patch, hipStream_t s) {
+    const long long total = (long long)B * C * h * w * patch * patch;
+    if (total < 1) return 1;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks), dim3(256), 0, s, in, in_dt, ld, nchw, B, C, h, w, patch);
+    return hipGetLastError() != hipSuccess;
+}
+
+// classifier-free guidance + flow-matching Euler step: v holds [negative ; positive] halves of n elements each when use_cfg,
+// x <- x + dsigma * (v_neg + g * (v_pos - v_neg))
+__global__ __launch_bounds__(256) void cfg_euler_kernel(const float* __restrict__ v, float* __restrict__ x, long long n, float g, float ds,
+                                                         int use_cfg) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float vv = v[i];
+        if (use_cfg) vv = vv + g * (v[n + i] - vv);
+        x[i] = x[i] + ds * vv;
+    }
+}
+
+int launch_cfg_euler(const float* v, float* x, int B, long long n, float guidance, float dsigma, int use_cfg, hipStream_t s) {
+    (void)B;
+    if (n < 1) return 1;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3(blocks), dim3(256), 0, s, v, x, n, guidance, dsigma, use_cfg);
+    return hipGetLastError() != hipSuccess;
+}

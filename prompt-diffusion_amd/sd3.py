@@ -1,0 +1,252 @@
+"""Host side of the SD3 / MMDiT variant of the path over the C ABI (pd_sd3_* in include/pdengine.h).
+
+Mirrors, at the tensor level, what the reference's SD3 pipeline does per denoising step
+(promptdiffusioncontrolnetpipeline_sd3.py:1192-1245): ControlNet (promptdiffusioncontrolnet_sd3.py:362-483), transformer
+with ``block_controlnet_hidden_states``, classifier-free guidance, FlowMatchEuler step.  Text encoders (CLIP-L, CLIP-G, T5),
+the VAE and ``down_proj`` / ``encode_support_pair`` stay with the caller: the boundary takes prompt embeddings and condition
+LATENTS.  PARITY UNPINNED (diffusers is absent offline): checked against oracle/sd3_oracle.py only."""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import engine as E
+from . import weights as W
+
+
+@dataclass(frozen=True)
+class SD3Config:
+    in_channels: int = 16
+    out_channels: int = 16
+    patch: int = 2
+    heads: int = 24
+    head_dim: int = 64
+    layers: int = 24
+    cn_layers: int = 6              # the reference class defaults to 18 (promptdiffusioncontrolnet_sd3.py:95); SD3 ControlNet
+                                    # checkpoints ship 6 or 12 blocks
+    joint_dim: int = 4096
+    pooled_dim: int = 2048
+    pos_embed_max_size: int = 192
+    cn_pos_embed_max_size: int = 0  # 0: same as the transformer's
+
+    @property
+    def hidden(self) -> int:
+        return self.heads * self.head_dim
+
+
+SD3_MEDIUM = SD3Config()
+SD3_TINY = SD3Config(in_channels=4, out_channels=4, heads=2, head_dim=64, layers=3, cn_layers=2, joint_dim=96, pooled_dim=40,
+                     pos_embed_max_size=12, cn_pos_embed_max_size=10)
+
+
+class pd_sd3_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_channels", "out_channels", "patch_size", "heads", "head_dim", "layers", "cn_layers",
+                                         "joint_dim", "pooled_dim", "pos_embed_max_size", "cn_pos_embed_max_size")] + \
+               [("reserved", C.c_int32 * 5)]
+
+
+class pd_sd3_args(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("context_len", C.c_int32), ("mem", C.c_int32),
+                ("conditioning_scale", C.c_float),
+                ("latents", C.c_void_p), ("timestep", C.c_void_p), ("context", C.c_void_p), ("pooled", C.c_void_p),
+                ("cond", C.c_void_p), ("pair", C.c_void_p), ("reserved", C.c_int64 * 4)]
+
+
+def flow_match_sigmas(steps: int, shift: float = 3.0, num_train_timesteps: int = 1000) -> np.ndarray:
+    """FlowMatchEulerDiscreteScheduler.set_timesteps(num_inference_steps) of the scheduler the reference pipeline holds
+    (promptdiffusioncontrolnetpipeline_sd3.py:1086-1088): sigmas[steps + 1], descending, last 0; timestep_i = 1000 sigma_i."""
+    shifted = lambda s: shift * s / (1.0 + (shift - 1.0) * s)
+    ts = np.linspace(shifted(1.0) * num_train_timesteps, shifted(1.0 / num_train_timesteps) * num_train_timesteps, steps)
+    return np.concatenate([shifted(ts / num_train_timesteps), [0.0]]).astype(np.float32)
+
+
+def sincos_pos_embed(dim: int, grid: int, base_size: int, interpolation_scale: float = 1.0) -> np.ndarray:
+    """The 2-D sin/cos table PatchEmbed registers as `pos_embed` ([grid * grid, dim]; first half of the channels encodes the
+    column, second half the row) -- real checkpoints carry it as a tensor; this is for synthetic weights."""
+    def axis(pos, d):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        ang = pos.reshape(-1)[:, None] * omega[None]
+        return np.concatenate([np.sin(ang), np.cos(ang)], axis=1)
+    g = np.arange(grid, dtype=np.float64) / (grid / base_size) / interpolation_scale
+    col, row = np.meshgrid(g, g)
+    return np.concatenate([axis(col, dim // 2), axis(row, dim // 2)], axis=1).astype(np.float32)
+
+
+def sd3_param_shapes(cfg: SD3Config) -> Dict[str, tuple]:
+    """diffusers state-dict names and shapes of both networks ("transformer." / "controlnet." prefixes)."""
+    D, out = cfg.hidden, {}
+
+    def lin(name, n, k):
+        out[name + ".weight"], out[name + ".bias"] = (n, k), (n,)
+
+    for net, layers, cn in (("transformer.", cfg.layers, False), ("controlnet.", cfg.cn_layers, True)):
+        if layers == 0:
+            continue
+        pm = cfg.cn_pos_embed_max_size if cn and cfg.cn_pos_embed_max_size else cfg.pos_embed_max_size
+        out[net + "pos_embed.proj.weight"], out[net + "pos_embed.proj.bias"] = (D, cfg.in_channels, cfg.patch, cfg.patch), (D,)
+        out[net + "pos_embed.pos_embed"] = (1, pm * pm, D)
+        if cn:
+            out[net + "pos_embed_input.proj.weight"] = (D, cfg.in_channels, cfg.patch, cfg.patch)
+            out[net + "pos_embed_input.proj.bias"] = (D,)
+        lin(net + "time_text_embed.timestep_embedder.linear_1", D, 256)
+        lin(net + "time_text_embed.timestep_embedder.linear_2", D, D)
+        lin(net + "time_text_embed.text_embedder.linear_1", D, cfg.pooled_dim)
+        lin(net + "time_text_embed.text_embedder.linear_2", D, D)
+        lin(net + "context_embedder", D, cfg.joint_dim)
+        for i in range(layers):
+            b = f"{net}transformer_blocks.{i}."
+            pre_only = (not cn) and i == layers - 1
+            lin(b + "norm1.linear", 6 * D, D)
+            lin(b + "norm1_context.linear", (2 if pre_only else 6) * D, D)
+            for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0"):
+                lin(b + "attn." + n, D, D)
+            lin(b + "ff.net.0.proj", 4 * D, D)
+            lin(b + "ff.net.2", D, 4 * D)
+            if not pre_only:
+                lin(b + "attn.to_add_out", D, D)
+                lin(b + "ff_context.net.0.proj", 4 * D, D)
+                lin(b + "ff_context.net.2", D, 4 * D)
+            if cn:
+                lin(f"{net}controlnet_blocks.{i}", D, D)
+        if not cn:
+            lin(net + "norm_out.linear", 2 * D, D)
+            lin(net + "proj_out", cfg.patch * cfg.patch * cfg.out_channels, D)
+    return out
+
+
+def synth_sd3_state_dict(cfg: SD3Config, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Deterministic non-degenerate weights (the zero-initialised modules get small non-zero values so that every branch
+    contributes); pos_embed.pos_embed is the real sin/cos table."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, shp in sd3_param_shapes(cfg).items():
+        if name.endswith("pos_embed.pos_embed"):
+            m = int(round(math.sqrt(shp[1])))
+            sd[name] = sincos_pos_embed(shp[2], m, base_size=max(1, m // 2))[None].astype(np.float32)
+        elif name.endswith(".bias"):
+            sd[name] = (0.05 * rng.standard_normal(shp)).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            scale = 0.5 if "norm1" in name or "norm_out" in name else 1.0     # keep the modulation gates moderate
+            sd[name] = (scale * rng.standard_normal(shp) / math.sqrt(fan_in)).astype(np.float32)
+    return sd
+
+
+class SD3Engine:
+    """The SD3 networks on one engine (one GPU, one stream).  NumPy arrays or CUDA torch tensors in, the same kind out."""
+
+    def __init__(self, cfg: SD3Config = SD3_MEDIUM, device: int = 0, precision: str = "f16", stream_f32: bool = False,
+                 lib_path: Optional[str] = None):
+        self.cfg = cfg
+        self.base = E.Engine(W.TINY, device=device, precision=precision, stream_f32=stream_f32, lib_path=lib_path)
+        lib = self.base.lib
+        lib.pd_sd3_configure.argtypes = [C.c_void_p, C.POINTER(pd_sd3_config)]
+        lib.pd_sd3_weights_missing.argtypes = [C.c_void_p]
+        lib.pd_sd3_forward.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_void_p]
+        lib.pd_sd3_control.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_int32, C.c_void_p]
+        lib.pd_sd3_sample.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
+        c = pd_sd3_config(cfg.in_channels, cfg.out_channels, cfg.patch, cfg.heads, cfg.head_dim, cfg.layers, cfg.cn_layers,
+                          cfg.joint_dim, cfg.pooled_dim, cfg.pos_embed_max_size, cfg.cn_pos_embed_max_size)
+        self.base._check(lib.pd_sd3_configure(self.base._h, C.byref(c)))
+
+    def close(self):
+        self.base.close()
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, strict: bool = True) -> None:
+        known = {n for n, _ in self.base.param_names()}
+        for name, arr in (sd.items() if isinstance(sd, dict) else sd):
+            if name in known and (name.startswith("transformer.") or name.startswith("controlnet.")):
+                self.base.load_tensor(name, arr)
+        if strict and self.weights_missing():
+            raise E.PdError(f"{self.weights_missing()} SD3 tensors missing after load_state_dict")
+
+    def init_random_weights(self, seed: int = 1234) -> None:
+        self.base.init_random_weights(seed)
+
+    def weights_missing(self) -> int:
+        return int(self.base.lib.pd_sd3_weights_missing(self.base._h))
+
+    # ------------------------------------------------------------------ calls
+    def _args(self, latents, context, pooled, cond, pair, scale, timestep=None, rows=None):
+        bufs = [E._Buf(x) for x in (latents, context, pooled, cond, pair)]
+        mems = {b.mem for b in bufs if b.mem is not None}
+        if len(mems) != 1:
+            raise ValueError("all tensors of one call must live in the same memory space (NumPy / CPU or one CUDA device)")
+        mem = mems.pop()
+        lat = bufs[0].owner
+        B, _, H, Wd = lat.shape
+        rows = rows or B
+        if tuple(bufs[1].owner.shape[::2]) != (rows, self.cfg.joint_dim) or tuple(bufs[2].owner.shape) != (rows, self.cfg.pooled_dim):
+            raise ValueError(f"context must be [{rows}, S, {self.cfg.joint_dim}] and pooled [{rows}, {self.cfg.pooled_dim}]")
+        for b in bufs[3:]:
+            if b.owner is not None and tuple(b.owner.shape) != tuple(lat.shape):
+                raise ValueError("cond / pair latents must have the shape of latents")
+        a = pd_sd3_args()
+        a.batch, a.height, a.width, a.context_len, a.mem = B, H, Wd, bufs[1].owner.shape[1], mem
+        a.conditioning_scale = float(scale)
+        a.latents, a.context, a.pooled, a.cond, a.pair = (b.ptr for b in bufs)
+        keep = bufs
+        if timestep is not None:
+            t = np.ascontiguousarray(np.broadcast_to(np.asarray(E._to_host(timestep), np.float32), (B,)))
+            a.timestep = t.ctypes.data
+            keep = bufs + [t]
+        self.base._order_after_torch(mem)
+        return a, keep, mem, lat
+
+    def _out(self, mem, like, shape):
+        if mem == E.PD_MEM_DEVICE:
+            import torch
+            o = torch.empty(shape, dtype=torch.float32, device=like.device)
+            return o, o.data_ptr()
+        o = np.empty(shape, np.float32)
+        return o, o.ctypes.data
+
+    def forward(self, latents, timestep, context, pooled, cond=None, pair=None, conditioning_scale: float = 1.0):
+        """One evaluation: transformer(latents, timestep, context, pooled | ControlNet(cond, pair) residuals) -> velocity."""
+        a, keep, mem, lat = self._args(latents, context, pooled, cond, pair, conditioning_scale, timestep)
+        out, ptr = self._out(mem, lat, (a.batch, self.cfg.out_channels, a.height, a.width))
+        self.base._check(self.base.lib.pd_sd3_forward(self.base._h, C.byref(a), ptr))
+        return out
+
+    def controlnet(self, latents, timestep, context, pooled, cond, pair, conditioning_scale: float = 1.0):
+        """SD3PromptDiffusionModel.forward: the list of cn_layers scaled residuals [B, N, hidden]."""
+        res = []
+        for i in range(self.cfg.cn_layers):
+            a, keep, mem, lat = self._args(latents, context, pooled, cond, pair, conditioning_scale, timestep)
+            n = (a.height // self.cfg.patch) * (a.width // self.cfg.patch)
+            out, ptr = self._out(mem, lat, (a.batch, n, self.cfg.hidden))
+            self.base._check(self.base.lib.pd_sd3_control(self.base._h, C.byref(a), i, ptr))
+            res.append(out)
+        return res
+
+    def sample(self, latents, prompt_embeds, pooled_prompt_embeds, negative_prompt_embeds=None, negative_pooled_prompt_embeds=None,
+               control_latents=None, pair_latents=None, num_inference_steps: int = 28, guidance_scale: float = 7.0,
+               controlnet_conditioning_scale: float = 1.0, shift: float = 3.0, sigmas=None):
+        """The denoising loop of the reference's __call__ (promptdiffusioncontrolnetpipeline_sd3.py:1192-1245) from initial
+        noise `latents` to final latents.  guidance_scale > 1 needs the negative embeddings (batch [negative ; positive])."""
+        cfg_on = guidance_scale > 1.0
+        if cfg_on and (negative_prompt_embeds is None or negative_pooled_prompt_embeds is None):
+            raise ValueError("guidance_scale > 1 needs negative_prompt_embeds and negative_pooled_prompt_embeds")
+        if cfg_on:
+            if E._is_torch(prompt_embeds):
+                import torch
+                ctx = torch.cat([negative_prompt_embeds, prompt_embeds], 0)
+                pooled = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], 0)
+            else:
+                ctx = np.concatenate([negative_prompt_embeds, prompt_embeds], 0)
+                pooled = np.concatenate([negative_pooled_prompt_embeds, pooled_prompt_embeds], 0)
+        else:
+            ctx, pooled = prompt_embeds, pooled_prompt_embeds
+        sig = flow_match_sigmas(num_inference_steps, shift) if sigmas is None else np.ascontiguousarray(sigmas, np.float32)
+        if sig.shape != (num_inference_steps + 1,):
+            raise ValueError("sigmas must hold num_inference_steps + 1 values")
+        B = latents.shape[0]
+        a, keep, mem, lat = self._args(latents, ctx, pooled, control_latents, pair_latents, controlnet_conditioning_scale,
+                                       rows=2 * B if cfg_on else B)
+        out, ptr = self._out(mem, lat, tuple(lat.shape))
+        self.base._check(self.base.lib.pd_sd3_sample(self.base._h, C.byref(a), sig.ctypes.data, num_inference_steps,
+                                                     float(guidance_scale), ptr))
+        return out
