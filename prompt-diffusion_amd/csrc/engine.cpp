@@ -677,10 +677,14 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         // stores of one tile overlapping the MFMAs of others, i.e. many waves per CU rather than a big tile -- the
         // 128 x 160 tile on 8 waves at <= 128 VGPRs runs 2 blocks = 16 waves per CU (+0.6 % end-to-end, interleaved A/B)
         if (opt_short_k > 0 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_short_k) p.big_tile = 2;
+        // widths that are multiples of 192 but not of 160 (MMDiT hidden size 1536 and its 3x / 4x): the 256 x 192 tile
+        if (opt_tile192 && !f32 && P != PREC_F16X2 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && m.N % 192 == 0 && m.N % 160 != 0 &&
+            ((p.M + 255) / 256) * (m.N / 192) >= 192)
+            p.big_tile = 4;
         if (P == PREC_F16X2 && m.geglu && p.big_tile == 3) p.big_tile = 1;   // the 256 x 320 GEGLU tile spills with the split-operand fragments
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
         if (ln_out && splitk == 1 && !m.geglu && !VT) {   // this launch's own epilogue leaves the row statistics
-            const int bn_cols = p.big_tile == 3 ? 320 : 160;
+            const int bn_cols = p.big_tile == 3 ? 320 : p.big_tile == 4 ? 192 : 160;
             ln_out->parts = ((m.N + bn_cols - 1) / bn_cols) * 2;   // 2 waves across N in every non-GEGLU tile
             ln_out->C = m.Nout;
             p.stats_out = ln_out->stats;

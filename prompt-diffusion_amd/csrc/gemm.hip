@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     constexpr bool F32 = prec_f32_storage(P);
     // register prefetch depth: two K steps ahead (two named staging sets) unless the fp32->bf16 staging
     // path already doubles the A registers
-    constexpr int DEPTH = (AF32 || BN > 160 || (BM == 128 && WM * WN == 8) || P == PREC_F16X2) ? 1 : 2;   // the 16-waves-per-CU shape has 128 VGPRs per wave
+    constexpr int DEPTH = (AF32 || BN > 192 || (BM == 128 && WM * WN == 8) || P == PREC_F16X2) ? 1 : 2;   // the 16-waves-per-CU shape has 128 VGPRs per wave
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int A_ITERS = BM * 8 / NTHREADS;                   // 16-byte chunks per thread per K step
     constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;  // last one masked when it does not divide
@@ -499,6 +499,15 @@ int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
         if (tile == 3) return launch_one<P, 256, 320, 4, 2, false, false, true>(p, s, mid);
         if (tile == 1) return launch_one<P, 256, 160, 8, 1, false, false, true>(p, s, mid);
         return launch_one<P, 128, 160, 4, 1, false, false, true>(p, s, mid);
+    }
+    if constexpr (!F) {
+        // 256 x 192 on 4 x 2 waves: the tile of widths that are multiples of 192 but not of 160 (MMDiT: 1536 = 8 x 192,
+        // 4608, 6144) -- no padded columns, and 8192 rows x 1536 columns is exactly one block per CU
+        if (tile == 4) {
+            if (conv || af32) return 1;
+            if (p.act == 4 || p.gate || p.c_sample_rows) return launch_one<P, 256, 192, 4, 2, false, false, false, true>(p, s, mid);
+            return launch_one<P, 256, 192, 4, 2, false, false, false, false>(p, s, mid);
+        }
     }
     if (p.act == 4 || p.gate || p.c_sample_rows) {   // MMDiT epilogue extras: linear layers over operands of the compute type
         if (conv || af32) return 1;

@@ -168,6 +168,12 @@ def test_headline_gemm_tiles_against_oracle(eng):
     x = g.standard_normal((M, K), dtype=np.float32)
     w = (g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
     assert relerr(eng.op_linear(x, w, None), O.linear(x, w)) < TOL[eng.prec]
+    # 256 x 192 tile (2-byte modes): widths that divide by 192 but not by 160 -- the MMDiT hidden size 1536; ragged M
+    M, K, N = 6144 + 37, 448, 1536
+    x = g.standard_normal((M, K), dtype=np.float32)
+    w = (g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = g.standard_normal(N, dtype=np.float32) * 0.1
+    assert relerr(eng.op_linear(x, w, b), O.linear(x, w, b)) < TOL[eng.prec]
 
 
 @pytest.mark.parametrize("B,C,H,W,eps,silu", [(2, 64, 8, 8, 1e-5, True), (3, 320, 16, 16, 1e-6, False),
