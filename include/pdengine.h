@@ -250,7 +250,9 @@ typedef struct pd_sd3_config {
     int32_t pooled_dim;         /* pooled_projection_dim 2048 */
     int32_t pos_embed_max_size; /* 192: side of the transformer's sin/cos table "transformer.pos_embed.pos_embed" */
     int32_t cn_pos_embed_max_size; /* the ControlNet's own table (promptdiffusioncontrolnet_sd3.py:102 default 96); 0: same */
-    int32_t reserved[5];
+    int32_t cn_zero_pooled;     /* force_zeros_for_pooled_projection (promptdiffusioncontrolnet_sd3.py:108, pipeline :1164-1168):
+                                   the ControlNet sees zero pooled projections; 0: cn_pooled, or pooled when that is NULL */
+    int32_t reserved[4];
 } pd_sd3_config;
 
 typedef struct pd_sd3_args {
@@ -265,7 +267,8 @@ typedef struct pd_sd3_args {
     const float* pooled;      /* [B, pooled_dim]    pooled_projections */
     const float* cond;        /* [B, C, H, W] controlnet_cond latents, or NULL: transformer alone */
     const float* pair;        /* [B, C, H, W] controlnet_example_pair_cond latents */
-    int64_t reserved[4];
+    const float* cn_pooled;   /* [B, pooled_dim] controlnet_pooled_projections, or NULL (see cn_zero_pooled) */
+    int64_t reserved[3];
 } pd_sd3_args;
 
 /* Registers the SD3 networks' parameters on an existing engine (any pd_config; the UNet path keeps working) and allocates
@@ -274,11 +277,17 @@ int pd_sd3_configure(pd_engine* e, const pd_sd3_config* cfg);
 int pd_sd3_weights_missing(pd_engine* e);
 /* One evaluation: velocity [B, out_channels, H, W] (fp32, args->mem) = transformer(latents | ControlNet residuals). */
 int pd_sd3_forward(pd_engine* e, const pd_sd3_args* args, float* v_out);
-/* ControlNet alone: residual i as [B, (H/p)(W/p), hidden] fp32, i in [0, cn_layers) (controlnet_block_samples). */
+/* ControlNet alone (the model-level call): residual i as [B, (H/p)(W/p), hidden] fp32, i in [0, cn_layers)
+ * (controlnet_block_samples); pooled projections = cn_pooled, or pooled when that is NULL -- cn_zero_pooled is the
+ * pipeline's choice and does not apply here. */
 int pd_sd3_control(pd_engine* e, const pd_sd3_args* args, int32_t index, float* out);
 /* The whole loop: sigmas[steps + 1] (host, descending, last = 0 for a full schedule); guidance > 1 runs the doubled batch
- * [negative ; positive]: context / pooled then hold 2B rows, latents / cond / pair B rows.  latents_out: [B, C, H, W]. */
-int pd_sd3_sample(pd_engine* e, const pd_sd3_args* args, const float* sigmas, int32_t steps, float guidance, float* latents_out);
+ * [negative ; positive]: context / pooled / cn_pooled then hold 2B rows, latents / cond / pair B rows.
+ * step_scales: per-step conditioning scale [steps] (host) = controlnet_conditioning_scale * controlnet_keep[i]
+ * (pipeline :1155-1162, :1202-1208), or NULL: args->conditioning_scale at every step; a step with scale 0 skips the
+ * ControlNet (its residuals would be all zero).  latents_out: [B, C, H, W]. */
+int pd_sd3_sample(pd_engine* e, const pd_sd3_args* args, const float* sigmas, int32_t steps, float guidance,
+                  const float* step_scales, float* latents_out);
 
 #ifdef __cplusplus
 }

@@ -187,8 +187,10 @@ def flow_match_sigmas(steps, shift=3.0, num_train=1000):
     return np.concatenate([s, [0.0]]).astype(F32)
 
 
-def sample(sd, cfg, latents, ctx, ctx_neg, pooled, pooled_neg, cond, pair, steps, guidance, scale=1.0, shift=3.0):
-    """pipeline :1192-1245: CFG-doubled batch ([negative, positive]), ControlNet then transformer, Euler step."""
+def sample(sd, cfg, latents, ctx, ctx_neg, pooled, pooled_neg, cond, pair, steps, guidance, scale=1.0, shift=3.0,
+           guidance_start=0.0, guidance_end=1.0, cn_pooled=None):
+    """pipeline :1155-1168, :1192-1245: CFG-doubled batch ([negative, positive]), ControlNet (zero pooled projections under
+    force_zeros_for_pooled_projection, scale * controlnet_keep[i]) then transformer, Euler step."""
     sig = flow_match_sigmas(steps, shift)
     x = latents
     B = x.shape[0]
@@ -196,7 +198,9 @@ def sample(sd, cfg, latents, ctx, ctx_neg, pooled, pooled_neg, cond, pair, steps
         t = np.full((2 * B,), sig[i] * 1000.0, F32)
         xi = np.concatenate([x, x])
         cc, pp = np.concatenate([ctx_neg, ctx]), np.concatenate([pooled_neg, pooled])
-        ctl = controlnet_forward(sd, cfg, xi, t, cc, pp, np.concatenate([cond, cond]), np.concatenate([pair, pair]), scale)
+        keep = 1.0 - float(i / steps < guidance_start or (i + 1) / steps > guidance_end)
+        cp = np.zeros_like(pp) if cfg.force_zeros_for_pooled_projection else (pp if cn_pooled is None else cn_pooled)
+        ctl = controlnet_forward(sd, cfg, xi, t, cc, cp, np.concatenate([cond, cond]), np.concatenate([pair, pair]), scale * keep)
         v = transformer_forward(sd, cfg, xi, t, cc, pp, ctl)
         v = v[:B] + F32(guidance) * (v[B:] - v[:B])
         x = (x + (sig[i + 1] - sig[i]) * v).astype(F32)

@@ -323,6 +323,7 @@ struct pd_engine {
     Sd3NetW sd3_tr, sd3_cn;
     struct Sd3Io {   // device pointers of one evaluation
         const float *latents, *context, *pooled, *cond, *pair;
+        const float* cn_pooled;   // ControlNet's pooled projections; null: zeros
         const float* t_host;
         int B, H, W, S;
         float scale;

@@ -150,8 +150,10 @@ int pd_engine::sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs
         HIP_OK(hipMemcpyAsync(sin_t.p, sv.data(), sv.size() * sizeof(float), hipMemcpyHostToDevice, stream));
         HIP_OK(hipStreamSynchronize(stream));   // sv is pageable host memory
         HIP_OK(hipMemsetAsync(pooled.p, 0, pooled.bytes(), stream));
-        HIP_OK(hipMemcpy2DAsync(pooled.p, (size_t)pooled.C * 4, io.pooled, (size_t)sd3.pooled_dim * 4, (size_t)sd3.pooled_dim * 4, B,
-                                hipMemcpyDeviceToDevice, stream));
+        const float* src = controlnet ? io.cn_pooled : io.pooled;   // ControlNet: null = zero pooled projections
+        if (src)
+            HIP_OK(hipMemcpy2DAsync(pooled.p, (size_t)pooled.C * 4, src, (size_t)sd3.pooled_dim * 4, (size_t)sd3.pooled_dim * 4, B,
+                                    hipMemcpyDeviceToDevice, stream));
     }
     PD_TRY(gemm(net.t1, sin_t, u, 1, 0, /*SiLU*/ 1, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
     PD_TRY(gemm(net.t2, u, temb, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
@@ -249,7 +251,7 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
     const int D = sd3.heads * sd3.head_dim, ps = sd3.patch_size, h = io.H / ps, w = io.W / ps, N = h * w, B = io.B;
     const size_t mk0 = arena.mark();
     std::vector<Act> control;
-    if (io.cond) {
+    if (io.cond && (io.scale != 0.f || control_index >= 0)) {   // scale 0 (controlnet_keep): every residual is zero
         Sd3NetW& net = sd3_cn;
         for (int i = 0; i < net.layers; ++i) control.push_back(new_act(B, N, 1, D, control_index >= 0 ? DT_F32 : S));
         const size_t mk = arena.mark();
@@ -387,7 +389,8 @@ int sd3_check(pd_engine* e, const pd_sd3_args* a, bool need_cond) {
 }
 
 // steps < 0: single evaluation (v_out or control residual); otherwise the Euler loop
-int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, float guidance, int control_index, float* out) {
+int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, float guidance, const float* step_scales,
+            int control_index, float* out) {
     HIP_OK(hipSetDevice(e->device));
     const bool loop = steps >= 0;
     const bool cfg = loop && guidance > 1.0f;
@@ -406,10 +409,11 @@ int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, 
     std::vector<float> t_host(Bf, 0.f);
     io.t_host = t_host.data();
     io.cond = a->cond; io.pair = a->pair;   // non-null markers for the dry run
+    io.scale = 1.f;                         // ... which always counts the ControlNet (a per-step scale may switch it on)
     Arena saved = e->arena;
     e->arena.base = nullptr; e->arena.cap = 0; e->arena.top = 0; e->arena.peak = 0; e->arena.dry = true; e->arena.overflow = false;
     int r = e->sd3_forward(io, nullptr, control_index, nullptr);
-    const size_t staged = (n_lat * 8 + n_ctx + n_pool + n_v + n_out) * sizeof(float) + 16 * 256;
+    const size_t staged = (n_lat * 8 + n_ctx + 2 * n_pool + n_v + n_out) * sizeof(float) + 16 * 256;
     const size_t need = e->arena.peak + staged + (64u << 20);
     e->arena = saved;
     e->arena.dry = false;
@@ -430,6 +434,10 @@ int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, 
     float* xin = cfg ? falloc(2 * n_lat) : x;       // doubled batch
     float* ctx = falloc(n_ctx);
     float* pool = falloc(n_pool);
+    // the ControlNet's pooled projections: zeros (force_zeros_for_pooled_projection), the caller's, or the transformer's
+    float* cn_pool = nullptr;
+    // (pd_sd3_control is the model-level call: the ControlNet gets what the caller hands it, like SD3PromptDiffusionModel.forward)
+    if (a->cond && (!e->sd3.cn_zero_pooled || control_index >= 0)) cn_pool = a->cn_pooled ? falloc(n_pool) : pool;
     float* cond = a->cond ? falloc(cfg ? 2 * n_lat : n_lat) : nullptr;
     float* pair = a->cond ? falloc(cfg ? 2 * n_lat : n_lat) : nullptr;
     float* v = falloc(n_v);
@@ -438,13 +446,15 @@ int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, 
     HIP_OK(hipMemcpyAsync(x, a->latents, n_lat * 4, kin, st));
     HIP_OK(hipMemcpyAsync(ctx, a->context, n_ctx * 4, kin, st));
     HIP_OK(hipMemcpyAsync(pool, a->pooled, n_pool * 4, kin, st));
+    if (cn_pool && cn_pool != pool) HIP_OK(hipMemcpyAsync(cn_pool, a->cn_pooled, n_pool * 4, kin, st));
     if (a->cond) {
         for (int d = 0; d < (cfg ? 2 : 1); ++d) {
             HIP_OK(hipMemcpyAsync(cond + d * n_lat, a->cond, n_lat * 4, kin, st));
             HIP_OK(hipMemcpyAsync(pair + d * n_lat, a->pair, n_lat * 4, kin, st));
         }
     }
-    io.latents = xin; io.context = ctx; io.pooled = pool; io.cond = cond; io.pair = pair;
+    io.scale = a->conditioning_scale;
+    io.latents = xin; io.context = ctx; io.pooled = pool; io.cn_pooled = cn_pool; io.cond = cond; io.pair = pair;
     if (!loop) {
         for (int b = 0; b < Bf; ++b) t_host[b] = a->timestep ? a->timestep[b] : 0.f;
         r = e->sd3_forward(io, v, control_index, res);
@@ -459,6 +469,7 @@ int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, 
                 HIP_OK(hipMemcpyAsync(xin + n_lat, x, n_lat * 4, hipMemcpyDeviceToDevice, st));
             }
             for (int b = 0; b < Bf; ++b) t_host[b] = sigmas[i] * 1000.0f;   // timestep = sigma * num_train_timesteps
+            if (step_scales) io.scale = step_scales[i];
             r = e->sd3_forward(io, v, -1, nullptr);
             if (r) break;
             ++e->launches;
@@ -481,17 +492,18 @@ int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, 
 extern "C" int pd_sd3_forward(pd_engine* e, const pd_sd3_args* a, float* v_out) {
     PD_TRY(sd3_check(e, a, false));
     if (!v_out || !a->timestep) { pd_set_error("pd_sd3_forward: v_out and timestep are required"); return 1; }
-    return sd3_run(e, a, nullptr, -1, 0.f, -1, v_out);
+    return sd3_run(e, a, nullptr, -1, 0.f, nullptr, -1, v_out);
 }
 
 extern "C" int pd_sd3_control(pd_engine* e, const pd_sd3_args* a, int32_t index, float* out) {
     PD_TRY(sd3_check(e, a, true));
     if (!out || !a->timestep || index < 0 || index >= e->sd3.cn_layers) { pd_set_error("pd_sd3_control: bad argument"); return 1; }
-    return sd3_run(e, a, nullptr, -1, 0.f, index, out);
+    return sd3_run(e, a, nullptr, -1, 0.f, nullptr, index, out);
 }
 
-extern "C" int pd_sd3_sample(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int32_t steps, float guidance, float* latents_out) {
+extern "C" int pd_sd3_sample(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int32_t steps, float guidance,
+                             const float* step_scales, float* latents_out) {
     PD_TRY(sd3_check(e, a, false));
     if (!sigmas || steps < 1 || !latents_out) { pd_set_error("pd_sd3_sample: sigmas, steps >= 1 and latents_out are required"); return 1; }
-    return sd3_run(e, a, sigmas, steps, guidance, -1, latents_out);
+    return sd3_run(e, a, sigmas, steps, guidance, step_scales, -1, latents_out);
 }

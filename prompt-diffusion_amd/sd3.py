@@ -30,6 +30,7 @@ class SD3Config:
     pooled_dim: int = 2048
     pos_embed_max_size: int = 192
     cn_pos_embed_max_size: int = 0  # 0: same as the transformer's
+    force_zeros_for_pooled_projection: bool = True   # the reference class's default (promptdiffusioncontrolnet_sd3.py:108)
 
     @property
     def hidden(self) -> int:
@@ -43,15 +44,16 @@ SD3_TINY = SD3Config(in_channels=4, out_channels=4, heads=2, head_dim=64, layers
 
 class pd_sd3_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_channels", "out_channels", "patch_size", "heads", "head_dim", "layers", "cn_layers",
-                                         "joint_dim", "pooled_dim", "pos_embed_max_size", "cn_pos_embed_max_size")] + \
-               [("reserved", C.c_int32 * 5)]
+                                         "joint_dim", "pooled_dim", "pos_embed_max_size", "cn_pos_embed_max_size",
+                                         "cn_zero_pooled")] + \
+               [("reserved", C.c_int32 * 4)]
 
 
 class pd_sd3_args(C.Structure):
     _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("context_len", C.c_int32), ("mem", C.c_int32),
                 ("conditioning_scale", C.c_float),
                 ("latents", C.c_void_p), ("timestep", C.c_void_p), ("context", C.c_void_p), ("pooled", C.c_void_p),
-                ("cond", C.c_void_p), ("pair", C.c_void_p), ("reserved", C.c_int64 * 4)]
+                ("cond", C.c_void_p), ("pair", C.c_void_p), ("cn_pooled", C.c_void_p), ("reserved", C.c_int64 * 3)]
 
 
 def flow_match_sigmas(steps: int, shift: float = 3.0, num_train_timesteps: int = 1000) -> np.ndarray:
@@ -146,9 +148,10 @@ class SD3Engine:
         lib.pd_sd3_weights_missing.argtypes = [C.c_void_p]
         lib.pd_sd3_forward.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_void_p]
         lib.pd_sd3_control.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_int32, C.c_void_p]
-        lib.pd_sd3_sample.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
+        lib.pd_sd3_sample.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
         c = pd_sd3_config(cfg.in_channels, cfg.out_channels, cfg.patch, cfg.heads, cfg.head_dim, cfg.layers, cfg.cn_layers,
-                          cfg.joint_dim, cfg.pooled_dim, cfg.pos_embed_max_size, cfg.cn_pos_embed_max_size)
+                          cfg.joint_dim, cfg.pooled_dim, cfg.pos_embed_max_size, cfg.cn_pos_embed_max_size,
+                          1 if cfg.force_zeros_for_pooled_projection else 0)
         self.base._check(lib.pd_sd3_configure(self.base._h, C.byref(c)))
 
     def close(self):
@@ -170,8 +173,8 @@ class SD3Engine:
         return int(self.base.lib.pd_sd3_weights_missing(self.base._h))
 
     # ------------------------------------------------------------------ calls
-    def _args(self, latents, context, pooled, cond, pair, scale, timestep=None, rows=None):
-        bufs = [E._Buf(x) for x in (latents, context, pooled, cond, pair)]
+    def _args(self, latents, context, pooled, cond, pair, scale, timestep=None, rows=None, cn_pooled=None):
+        bufs = [E._Buf(x) for x in (latents, context, pooled, cond, pair, cn_pooled)]
         mems = {b.mem for b in bufs if b.mem is not None}
         if len(mems) != 1:
             raise ValueError("all tensors of one call must live in the same memory space (NumPy / CPU or one CUDA device)")
@@ -181,13 +184,15 @@ class SD3Engine:
         rows = rows or B
         if tuple(bufs[1].owner.shape[::2]) != (rows, self.cfg.joint_dim) or tuple(bufs[2].owner.shape) != (rows, self.cfg.pooled_dim):
             raise ValueError(f"context must be [{rows}, S, {self.cfg.joint_dim}] and pooled [{rows}, {self.cfg.pooled_dim}]")
-        for b in bufs[3:]:
+        for b in bufs[3:5]:
             if b.owner is not None and tuple(b.owner.shape) != tuple(lat.shape):
                 raise ValueError("cond / pair latents must have the shape of latents")
+        if bufs[5].owner is not None and tuple(bufs[5].owner.shape) != (rows, self.cfg.pooled_dim):
+            raise ValueError(f"controlnet_pooled_projections must be [{rows}, {self.cfg.pooled_dim}]")
         a = pd_sd3_args()
         a.batch, a.height, a.width, a.context_len, a.mem = B, H, Wd, bufs[1].owner.shape[1], mem
         a.conditioning_scale = float(scale)
-        a.latents, a.context, a.pooled, a.cond, a.pair = (b.ptr for b in bufs)
+        a.latents, a.context, a.pooled, a.cond, a.pair, a.cn_pooled = (b.ptr for b in bufs)
         keep = bufs
         if timestep is not None:
             t = np.ascontiguousarray(np.broadcast_to(np.asarray(E._to_host(timestep), np.float32), (B,)))
@@ -204,18 +209,23 @@ class SD3Engine:
         o = np.empty(shape, np.float32)
         return o, o.ctypes.data
 
-    def forward(self, latents, timestep, context, pooled, cond=None, pair=None, conditioning_scale: float = 1.0):
-        """One evaluation: transformer(latents, timestep, context, pooled | ControlNet(cond, pair) residuals) -> velocity."""
-        a, keep, mem, lat = self._args(latents, context, pooled, cond, pair, conditioning_scale, timestep)
+    def forward(self, latents, timestep, context, pooled, cond=None, pair=None, conditioning_scale: float = 1.0,
+                controlnet_pooled_projections=None):
+        """One evaluation: transformer(latents, timestep, context, pooled | ControlNet(cond, pair) residuals) -> velocity.
+        The ControlNet's pooled projections are zeros under force_zeros_for_pooled_projection (the reference default), else
+        `controlnet_pooled_projections`, else `pooled` (pipeline :1164-1168)."""
+        a, keep, mem, lat = self._args(latents, context, pooled, cond, pair, conditioning_scale, timestep,
+                                       cn_pooled=controlnet_pooled_projections)
         out, ptr = self._out(mem, lat, (a.batch, self.cfg.out_channels, a.height, a.width))
         self.base._check(self.base.lib.pd_sd3_forward(self.base._h, C.byref(a), ptr))
         return out
 
     def controlnet(self, latents, timestep, context, pooled, cond, pair, conditioning_scale: float = 1.0):
-        """SD3PromptDiffusionModel.forward: the list of cn_layers scaled residuals [B, N, hidden]."""
+        """SD3PromptDiffusionModel.forward: the list of cn_layers scaled residuals [B, N, hidden].  `pooled` is what the
+        ControlNet itself is given (the pipeline passes zeros under force_zeros_for_pooled_projection)."""
         res = []
         for i in range(self.cfg.cn_layers):
-            a, keep, mem, lat = self._args(latents, context, pooled, cond, pair, conditioning_scale, timestep)
+            a, keep, mem, lat = self._args(latents, context, pooled, cond, pair, conditioning_scale, timestep, cn_pooled=pooled)
             n = (a.height // self.cfg.patch) * (a.width // self.cfg.patch)
             out, ptr = self._out(mem, lat, (a.batch, n, self.cfg.hidden))
             self.base._check(self.base.lib.pd_sd3_control(self.base._h, C.byref(a), i, ptr))
@@ -224,7 +234,8 @@ class SD3Engine:
 
     def sample(self, latents, prompt_embeds, pooled_prompt_embeds, negative_prompt_embeds=None, negative_pooled_prompt_embeds=None,
                control_latents=None, pair_latents=None, num_inference_steps: int = 28, guidance_scale: float = 7.0,
-               controlnet_conditioning_scale: float = 1.0, shift: float = 3.0, sigmas=None):
+               controlnet_conditioning_scale: float = 1.0, shift: float = 3.0, sigmas=None, control_guidance_start: float = 0.0,
+               control_guidance_end: float = 1.0, controlnet_pooled_projections=None):
         """The denoising loop of the reference's __call__ (promptdiffusioncontrolnetpipeline_sd3.py:1192-1245) from initial
         noise `latents` to final latents.  guidance_scale > 1 needs the negative embeddings (batch [negative ; positive])."""
         cfg_on = guidance_scale > 1.0
@@ -245,8 +256,13 @@ class SD3Engine:
             raise ValueError("sigmas must hold num_inference_steps + 1 values")
         B = latents.shape[0]
         a, keep, mem, lat = self._args(latents, ctx, pooled, control_latents, pair_latents, controlnet_conditioning_scale,
-                                       rows=2 * B if cfg_on else B)
+                                       rows=2 * B if cfg_on else B, cn_pooled=controlnet_pooled_projections)
+        # controlnet_keep (pipeline :1155-1162): the ControlNet acts on the steps inside [start, end] of the schedule
+        n = num_inference_steps
+        keep_steps = np.array([1.0 - float(i / n < control_guidance_start or (i + 1) / n > control_guidance_end) for i in range(n)],
+                              np.float32)
+        scales = np.ascontiguousarray(keep_steps * np.float32(controlnet_conditioning_scale))
         out, ptr = self._out(mem, lat, tuple(lat.shape))
         self.base._check(self.base.lib.pd_sd3_sample(self.base._h, C.byref(a), sig.ctypes.data, num_inference_steps,
-                                                     float(guidance_scale), ptr))
+                                                     float(guidance_scale), scales.ctypes.data, ptr))
         return out

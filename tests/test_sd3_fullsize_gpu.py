@@ -47,7 +47,7 @@ def test_f16_against_the_fp32_class_mode(eng):
     assert np.isfinite(v16).all() and np.isfinite(v32).all()
     e_v, e_c = relerr(v16, v32), max(relerr(a, b) for a, b in zip(c16, c32))
     print("SD3-medium f16 vs f16x2: velocity %.2e, control residuals %.2e" % (e_v, e_c))
-    assert e_v < 2e-2 and e_c < 2e-2
+    assert e_v < 5e-3 and e_c < 5e-3      # measured 1.5e-3 / 8.5e-4
 
 
 def test_properties_at_full_size(eng):

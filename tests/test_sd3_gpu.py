@@ -54,10 +54,12 @@ def test_transformer_alone(eng, sd, B, H, W, S):
 def test_controlnet_residuals_and_steered_velocity(eng, sd, B, H, W, S):
     i = inputs(B, H, W, S, seed=10 + B)
     ctl = O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 0.8)
-    got_ctl = eng.controlnet(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 0.8)
+    got_ctl = eng.controlnet(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 0.8)   # model-level call: pooled as given
     assert len(got_ctl) == CFG.cn_layers
     for g, r in zip(got_ctl, ctl):
         assert relerr(g, r) < TOL[eng.prec]
+    # the pipeline-level evaluation hands the ControlNet ZERO pooled projections (force_zeros_for_pooled_projection)
+    ctl = O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], np.zeros_like(i["pooled"]), i["cond"], i["pair"], 0.8)
     ref = O.transformer_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], ctl)
     got = eng.forward(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 0.8)
     assert relerr(got, ref) < TOL[eng.prec]
@@ -79,13 +81,42 @@ def test_sampling_loop_with_guidance(eng, sd):
     assert relerr(got1, ref1) < 3 * TOL[eng.prec]
 
 
+def test_controlnet_pooled_projections_and_guidance_window(sd):
+    """force_zeros_for_pooled_projection = False: the ControlNet gets controlnet_pooled_projections, or the transformer's
+    (pipeline :1164-1168); control_guidance_start / end switch the ControlNet off outside their window (:1155-1162)."""
+    import dataclasses
+    cfg = dataclasses.replace(CFG, force_zeros_for_pooled_projection=False)
+    e = sd3.SD3Engine(cfg, precision="f32")
+    e.load_state_dict(sd)
+    i, o = inputs(2, 8, 8, 6, seed=61), inputs(2, 8, 8, 6, seed=62)
+    for cn_pooled in (None, o["pooled"]):
+        ctl = O.controlnet_forward(sd, cfg, i["x"], i["t"], i["ctx"], i["pooled"] if cn_pooled is None else cn_pooled, i["cond"], i["pair"])
+        ref = O.transformer_forward(sd, cfg, i["x"], i["t"], i["ctx"], i["pooled"], ctl)
+        got = e.forward(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], controlnet_pooled_projections=cn_pooled)
+        assert relerr(got, ref) < 2e-4
+    e.close()
+    e = sd3.SD3Engine(CFG, precision="f32")
+    e.load_state_dict(sd)
+    i, n = inputs(1, 8, 8, 5, seed=63), inputs(1, 8, 8, 5, seed=64)
+    kw = dict(steps=4, guidance=4.0, scale=0.9)
+    for lo, hi in ((0.0, 0.5), (0.25, 1.0), (0.3, 0.7)):
+        ref = O.sample(sd, CFG, i["x"], i["ctx"], n["ctx"], i["pooled"], n["pooled"], i["cond"], i["pair"], guidance_start=lo,
+                       guidance_end=hi, **kw)
+        got = e.sample(i["x"], i["ctx"], i["pooled"], n["ctx"], n["pooled"], i["cond"], i["pair"], num_inference_steps=4,
+                       guidance_scale=4.0, controlnet_conditioning_scale=0.9, control_guidance_start=lo, control_guidance_end=hi)
+        assert relerr(got, ref) < 6e-4
+    full = O.sample(sd, CFG, i["x"], i["ctx"], n["ctx"], i["pooled"], n["pooled"], i["cond"], i["pair"], **kw)
+    assert relerr(full, ref) > 1e-3          # the window matters
+    e.close()
+
+
 def test_cuda_tensors_in_and_out(sd):
     import torch
     e = sd3.SD3Engine(CFG, precision="f32")
     e.load_state_dict(sd)
     i = inputs(2, 8, 8, 6, seed=31)
     ref = O.transformer_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"],
-                                O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"]))
+                                O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], 0 * i["pooled"], i["cond"], i["pair"]))
     d = {k: torch.from_numpy(v).cuda() for k, v in i.items()}
     got = e.forward(d["x"], d["t"], d["ctx"], d["pooled"], d["cond"], d["pair"])
     assert got.is_cuda and relerr(got.cpu().numpy(), ref) < 2e-4
@@ -98,7 +129,7 @@ def test_stream_f32_option(sd):
     """fp32 residual streams with 2-byte MFMA operands: closer to the oracle than the plain f16 mode."""
     i = inputs(2, 8, 12, 9, seed=41)
     ref = O.transformer_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"],
-                                O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"]))
+                                O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], 0 * i["pooled"], i["cond"], i["pair"]))
     errs = {}
     for sf in (False, True):
         e = sd3.SD3Engine(CFG, precision="f16", stream_f32=sf)

@@ -100,7 +100,7 @@ def test_guidance_identities():
     assert np.allclose(a, b, atol=1e-4)
     # one Euler step over the whole interval: x + (0 - 1) * v
     v = O.transformer_forward(sd, CFG, x, np.array([1000.0], np.float32), ctx, pooled,
-                              O.controlnet_forward(sd, CFG, x, np.array([1000.0], np.float32), ctx, pooled, cond, pair))
+                              O.controlnet_forward(sd, CFG, x, np.array([1000.0], np.float32), ctx, 0 * pooled, cond, pair))
     assert np.allclose(O.sample(sd, CFG, x, ctx, ctx, pooled, pooled, cond, pair, 1, 1.0), x - v, atol=1e-5)
 
 
@@ -108,5 +108,5 @@ def test_struct_layout_matches_header():
     """ctypes mirrors of pd_sd3_config / pd_sd3_args against the C header (sizes by the C compiler's rules)."""
     import ctypes as C
     assert C.sizeof(sd3.pd_sd3_config) == 16 * 4
-    assert C.sizeof(sd3.pd_sd3_args) == 6 * 4 + 6 * 8 + 4 * 8
-    assert sd3.pd_sd3_args.latents.offset == 24 and sd3.pd_sd3_args.pair.offset == 64
+    assert C.sizeof(sd3.pd_sd3_args) == 6 * 4 + 7 * 8 + 3 * 8
+    assert sd3.pd_sd3_args.latents.offset == 24 and sd3.pd_sd3_args.pair.offset == 64 and sd3.pd_sd3_args.cn_pooled.offset == 72
