@@ -616,7 +616,27 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.gn_silu = gn_silu ? 1 : 0;
     p.gate = gx.gate; p.gate_stride = gx.gate_stride;
     p.c_sample_rows = gx.c_sample_rows; p.c_row_off = gx.c_row_off; p.vt_tok_off = gx.vt_tok_off;
+    p.a_sample_rows = gx.a_sample_rows; p.a_row_off = gx.a_row_off;
+    const bool plain = !gx.gate && !gx.c_sample_rows && !gx.a_sample_rows;
     gx = GemmExtra{};
+    // a handful of fp32 rows against a wide weight matrix: stream the weights once (gemm.hip's tiles would spend a 128-row
+    // tile on <= 4 rows and run at a third of the HBM rate)
+    if (opt_gemv && plain && p.M <= 4 && m.taps == 1 && in.dt == DT_F32 && out.dt == DT_F32 && !R && !rowvec && !VT && act == 0 &&
+        !m.geglu && scale == 1.f && !ln_in && !ln_out && m.K % 8 == 0 && m.K <= 2048 && m.N >= 4096) {
+        if (arena.dry) return 0;
+        PD_TRY(check_arena());
+        ++launches;
+        ProfRec rec{};
+        if (profiling) {
+            prof_begin(rec, 1, 2.0 * (double)p.M * (double)m.Nout * (double)m.cin);
+            rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.taps = 10;
+        }
+        const int r = launch_gemv(reinterpret_cast<const float*>(in.p), in.C, m.w, T, m.Kpad, m.bias, reinterpret_cast<float*>(out.p), p.ldc,
+                                  p.M, m.N, m.K, a_silu ? 1 : 0, stream);
+        if (profiling) prof_end(rec);
+        if (r) { pd_set_error("gemv launch failed"); return 1; }
+        return 0;
+    }
     if (ln_in) {   // LayerNorm of `in` folded into this layer: raw A, folded weights, statistics from the producer
         if (!m.w_ln) { pd_set_error("internal: folded LayerNorm weights missing"); return 1; }
         p.W = m.w_ln;
@@ -825,7 +845,7 @@ int pd_engine::layernorm(const Act& x, Act& y, const float* g, const float* b) {
 }
 
 int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B,
-                         int Nq, int Nk, int C, int heads, bool causal, long long q_bs, long long k_bs) {
+                         int Nq, int Nk, int C, int heads, bool causal, long long q_bs, long long k_bs, long long o_bs) {
     if (heads <= 0) heads = cfg.num_heads;
     if (arena.dry) return 0;
     PD_TRY(check_arena());
@@ -835,7 +855,7 @@ int pd_engine::attention(const void* Q, int ldq, const void* K, int ldk, const v
     p.q_bs = q_bs ? q_bs : (long long)Nq * ldq;   // explicit strides: queries / keys that are row ranges of a larger buffer
     p.k_bs = k_bs ? k_bs : (long long)Nk * ldk;
     p.vt_bs = (long long)C * vt_ld;
-    p.o_bs = (long long)Nq * ldo;
+    p.o_bs = o_bs ? o_bs : (long long)Nq * ldo;
     p.Nq = Nq; p.Nk = Nk; p.heads = heads; p.dh = C / heads;
     p.causal = causal ? 1 : 0;
     p.scale = (float)(1.0 / std::sqrt((double)p.dh));

@@ -330,10 +330,11 @@ struct pd_engine {
     };
     void build_sd3_net(const std::string& prefix, Sd3NetW& net, bool controlnet);
     int sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs, Act& c, Act& modbuf);
-    int sd3_block(Sd3NetW& net, const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, int heads);
+    int sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt);
     int sd3_forward(const Sd3Io& io, float* v_out_dev, int control_index, float* control_out_dev);
     // one-shot extras of the next gemm() call (MMDiT: gated residual, joint-buffer row remap)
-    struct GemmExtra { const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0; } gx;
+    struct GemmExtra { const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0, a_sample_rows = 0, a_row_off = 0; } gx;
+    bool opt_gemv = true;     // Linear over <= 4 fp32 rows with a wide output (MMDiT modulation): weight-streaming kernel instead of a GEMM tile
 
     // weights
     int load(const char* name, const void* data, const int64_t* shape, int ndim, int dtype);
@@ -359,7 +360,7 @@ struct pd_engine {
     int resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride);
     int transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv);
     int attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B, int Nq,
-                  int Nk, int C, int heads = 0, bool causal = false, long long q_bs = 0, long long k_bs = 0);
+                  int Nk, int C, int heads = 0, bool causal = false, long long q_bs = 0, long long k_bs = 0, long long o_bs = 0);
 
     // networks
     int run_controlnet(const Act& x_in, int emb_row, int emb_stride, const float* scales);

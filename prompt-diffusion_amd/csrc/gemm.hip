@@ -96,6 +96,12 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             a_base[i] = 0;
         } else {
             a_base[i] = (size_t)mm * p.lda;
+            if constexpr (MM) {
+                if (p.a_sample_rows) {   // this token stream's rows inside a joint [sample][a_sample_rows] buffer
+                    const int b = mm / p.rows_per_sample;
+                    a_base[i] = (size_t)(b * p.a_sample_rows + p.a_row_off + (mm - b * p.rows_per_sample)) * p.lda;
+                }
+            }
             a_pix[i] = a_y[i] = a_x[i] = 0;
         }
     }
@@ -505,11 +511,11 @@ int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
         // 4608, 6144) -- no padded columns, and 8192 rows x 1536 columns is exactly one block per CU
         if (tile == 4) {
             if (conv || af32) return 1;
-            if (p.act == 4 || p.gate || p.c_sample_rows) return launch_one<P, 256, 192, 4, 2, false, false, false, true>(p, s, mid);
+            if (p.act == 4 || p.gate || p.c_sample_rows || p.a_sample_rows) return launch_one<P, 256, 192, 4, 2, false, false, false, true>(p, s, mid);
             return launch_one<P, 256, 192, 4, 2, false, false, false, false>(p, s, mid);
         }
     }
-    if (p.act == 4 || p.gate || p.c_sample_rows) {   // MMDiT epilogue extras: linear layers over operands of the compute type
+    if (p.act == 4 || p.gate || p.c_sample_rows || p.a_sample_rows) {   // MMDiT epilogue extras: linear layers over operands of the compute type
         if (conv || af32) return 1;
         if constexpr (F) {
             if (tile == 1 || tile == 3) return launch_one<P, 256, 160, 4, 2, false, false, false, true>(p, s, mid);

@@ -188,6 +188,9 @@ struct GemmParams {
     const float* gate;
     int gate_stride;
     int c_sample_rows, c_row_off, vt_tok_off;
+    // ... and of the A rows (linear, MM instantiations): row = sample * a_sample_rows + a_row_off + tok -- one token stream
+    // read out of a joint buffer (a_sample_rows = 0: row = m)
+    int a_sample_rows, a_row_off;
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
@@ -204,6 +207,10 @@ struct AttnParams {
 };
 
 int launch_gemm(const GemmParams& p, int prec, hipStream_t s, hipEvent_t mid = nullptr);   // prec: the compute type (DT_*)
+// y[b][n] = bias[n] + sum_k W[n][k] * f(a[b][k]) for B <= 4 fp32 rows (f = SiLU when a_silu): the weight-streaming form of
+// a Linear over a handful of rows (MMDiT modulation vectors); w_dt: DT_F32 / DT_F16 / DT_BF16, K % 8 == 0, K <= 2048
+int launch_gemv(const float* a, int lda, const void* W, int w_dt, int Kpad, const float* bias, float* y, int ldy, int B, int N, int K,
+                int a_silu, hipStream_t s);
 int gemm_tiles(int M, int N);
 int launch_splitk_finalize(const GemmParams& p, hipStream_t s);   // sums p.splitk fp32 slabs in slice order + epilogue
 int conv_patch_tiles(const GemmParams& p, int prec);  // 0: shape not eligible for the LDS-patch conv kernel

@@ -175,12 +175,14 @@ int pd_engine::sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs
     return 0;
 }
 
-// JointTransformerBlock.forward (diffusers attention.py; MMDiT block of Esser et al. Fig. 2b); x, c updated in place
-int pd_engine::sd3_block(Sd3NetW& net, const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, int heads) {
-    const int D = x.C, B = x.B, N = x.H, Sx = c.H, Nt = N + Sx;
+// JointTransformerBlock.forward (diffusers attention.py; MMDiT block of Esser et al. Fig. 2b); x, c updated in place.
+// qk: joint q|k buffer [B, N + S, 2D]; vt: joint V^T [B, D, pad(N + S)] with zeroed pad columns (both owned by the caller:
+// the same pair serves every block of a network, so the pad is cleared once per evaluation).
+int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt) {
+    const int D = x.C, B = x.B, N = x.H, Sx = c.H, Nt = N + Sx, heads = sd3.heads;
     const size_t eb = dt_size(T);
     const float* mod = reinterpret_cast<const float*>(modbuf.p);
-    const int ms = modbuf.C;
+    const int ms = modbuf.C, vt_ld = vt.C;
     const size_t mk = arena.mark();
     auto adaln = [&](const Act& in, Act& out, int shift_off, int scale_off) -> int {
         if (arena.dry) return 0;
@@ -196,11 +198,7 @@ int pd_engine::sd3_block(Sd3NetW& net, const Sd3BlockW& b, Act& x, Act& c, const
     PD_TRY(adaln(x, xn, b.mod_off, b.mod_off + D));                         // (shift_msa, scale_msa, gate_msa, shift_mlp, ...)
     if (b.pre_only) PD_TRY(adaln(c, cn, b.mod_c_off + D, b.mod_c_off));     // AdaLayerNormContinuous: (scale, shift)
     else PD_TRY(adaln(c, cn, b.mod_c_off, b.mod_c_off + D));
-    // joint q|k [B, N + S, 2D] and V^T [B, D, pad(N + S)]: both QKV GEMMs store straight into them
-    const int vt_ld = round_up(Nt, 8);
-    Act qk = new_act(B, Nt, 1, 2 * D, T);
-    Act vt = new_act(B, D, 1, vt_ld, T);
-    if (!arena.dry && vt_ld != Nt) HIP_OK(hipMemsetAsync(vt.p, 0, vt.bytes(), stream));   // pad keys of V^T must read as 0
+    // both QKV GEMMs store straight into the joint buffers
     {
         Act o = qk; o.H = N;
         gx.c_sample_rows = Nt; gx.c_row_off = 0; gx.vt_tok_off = 0;
@@ -209,18 +207,18 @@ int pd_engine::sd3_block(Sd3NetW& net, const Sd3BlockW& b, Act& x, Act& c, const
         gx.c_sample_rows = Nt; gx.c_row_off = N; gx.vt_tok_off = N;
         PD_TRY(gemm(b.qkv_c, cn, o, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * D, vt_ld));
     }
+    // ONE attention launch over the joint sequence (image queries only in the context_pre_only block); the out-projections
+    // read their token stream out of the joint output through the A-row remap
     const char* qkp = reinterpret_cast<const char*>(qk.p);
     const long long bs = (long long)Nt * 2 * D;
-    Act att = new_act(B, N, 1, D, T);
-    PD_TRY(attention(qkp, 2 * D, qkp + (size_t)D * eb, 2 * D, vt.p, vt_ld, att.p, D, B, N, Nt, D, heads, false, bs, bs));
-    gx.gate = mod + b.mod_off + 2 * D; gx.gate_stride = ms;
+    const int Nq = b.pre_only ? N : Nt;
+    Act att = new_act(B, Nt, 1, D, T);
+    PD_TRY(attention(qkp, 2 * D, qkp + (size_t)D * eb, 2 * D, vt.p, vt_ld, att.p, D, B, Nq, Nt, D, heads, false, bs, bs, (long long)Nt * D));
+    gx.gate = mod + b.mod_off + 2 * D; gx.gate_stride = ms; gx.a_sample_rows = Nt; gx.a_row_off = 0;
     PD_TRY(gemm(b.out, att, x, 1, 0, 0, 1.f, &x, nullptr, 0, false, nullptr, 0, 0));       // x += gate_msa * to_out(o_x)
     if (!b.pre_only) {
-        Act attc = new_act(B, Sx, 1, D, T);
-        PD_TRY(attention(qkp + (size_t)N * 2 * D * eb, 2 * D, qkp + (size_t)D * eb, 2 * D, vt.p, vt_ld, attc.p, D, B, Sx, Nt, D, heads,
-                         false, bs, bs));
-        gx.gate = mod + b.mod_c_off + 2 * D; gx.gate_stride = ms;
-        PD_TRY(gemm(b.out_c, attc, c, 1, 0, 0, 1.f, &c, nullptr, 0, false, nullptr, 0, 0));
+        gx.gate = mod + b.mod_c_off + 2 * D; gx.gate_stride = ms; gx.a_sample_rows = Nt; gx.a_row_off = N;
+        PD_TRY(gemm(b.out_c, att, c, 1, 0, 0, 1.f, &c, nullptr, 0, false, nullptr, 0, 0));
     }
     arena.release(mk);
     // feed-forward of each stream
@@ -242,7 +240,6 @@ int pd_engine::sd3_block(Sd3NetW& net, const Sd3BlockW& b, Act& x, Act& c, const
         PD_TRY(gemm(b.ffc2, f, c, 1, 0, 0, 1.f, &c, nullptr, 0, false, nullptr, 0, 0));
         arena.release(mk);
     }
-    (void)net;
     return 0;
 }
 
@@ -255,10 +252,16 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
         Sd3NetW& net = sd3_cn;
         for (int i = 0; i < net.layers; ++i) control.push_back(new_act(B, N, 1, D, control_index >= 0 ? DT_F32 : S));
         const size_t mk = arena.mark();
-        Act hs, c, modbuf;
+        Act hs, c, modbuf, qk, vt;
         PD_TRY(sd3_embed(net, io, true, hs, c, modbuf));
+        {
+            const int Nt = N + io.S, vt_ld = round_up(Nt, 8);
+            qk = new_act(B, Nt, 1, 2 * D, T);
+            vt = new_act(B, D, 1, vt_ld, T);
+            if (!arena.dry && vt_ld != Nt) HIP_OK(hipMemsetAsync(vt.p, 0, vt.bytes(), stream));   // pad keys of V^T must read as 0
+        }
         for (int i = 0; i < net.layers; ++i) {
-            PD_TRY(sd3_block(net, net.blocks[i], hs, c, modbuf, sd3.heads));
+            PD_TRY(sd3_block(net.blocks[i], hs, c, modbuf, qk, vt));
             // controlnet_blocks[i](hidden_states) * conditioning_scale   (:469-474)
             Act in = hs;
             if (hs.dt != T) {   // stream_f32: the zero Linear reads 2-byte operands
@@ -283,11 +286,17 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
         return 0;
     }
     Sd3NetW& net = sd3_tr;
-    Act hs, c, modbuf;
+    Act hs, c, modbuf, qk, vt;
     PD_TRY(sd3_embed(net, io, false, hs, c, modbuf));
+    {
+        const int Nt = N + io.S, vt_ld = round_up(Nt, 8);
+        qk = new_act(B, Nt, 1, 2 * D, T);
+        vt = new_act(B, D, 1, vt_ld, T);
+        if (!arena.dry && vt_ld != Nt) HIP_OK(hipMemsetAsync(vt.p, 0, vt.bytes(), stream));   // pad keys of V^T must read as 0
+    }
     const int interval = control.empty() ? 0 : (net.layers + (int)control.size() - 1) / (int)control.size();
     for (int i = 0; i < net.layers; ++i) {
-        PD_TRY(sd3_block(net, net.blocks[i], hs, c, modbuf, sd3.heads));
+        PD_TRY(sd3_block(net.blocks[i], hs, c, modbuf, qk, vt));
         if (interval && !net.blocks[i].pre_only) {   // hidden_states + block_controlnet_hidden_states[i // interval]
             if (!arena.dry) {
                 ++launches;

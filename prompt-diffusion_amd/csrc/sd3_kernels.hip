@@ -163,3 +163,115 @@ int launch_cfg_euler(const float* v, float* x, int B, long long n, float guidanc
     hipLaunchKernelGGL(cfg_euler_kernel, dim3(blocks), dim3(256), 0, s, v, x, n, guidance, dsigma, use_cfg);
     return hipGetLastError() != hipSuccess;
 }
+
+// Linear over B <= 4 fp32 rows: y[b][n] = bias[n] + sum_k W[n][k] * f(a[b][k]).  HBM-bound on W (the MMDiT modulation matrix
+// is 1.36 GB in fp16 and is read once per evaluation): one wave per output row at a time, the activation slices a lane
+// multiplies with held in registers for the whole kernel, UNROLL rows of 16-byte weight loads in flight per wave.
+template <int WD, int NB, int KC>   // KC: 512-element chunks of K (K <= 512 * KC)
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ a, int lda, const void* __restrict__ W, int Kpad,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int ldy, int N, int K,
+                                                         int a_silu) {
+    constexpr int EB = WD == DT_F32 ? 4 : 2;
+    constexpr int UNROLL = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    // activation slices of this lane: vector loads from a clamped address (lanes past K hold zeros, which also makes the
+    // weight values they fetch below irrelevant)
+    float av[NB][KC][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = c * 512 + lane * 8;
+            const bool ok = k < K;
+            const float* ap = a + (size_t)b * lda + (ok ? k : 0);
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ap), hi = *reinterpret_cast<const f32x4*>(ap + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = j < 4 ? lo[j] : hi[j - 4];
+                if (a_silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                av[b][c][j] = ok ? v : 0.f;
+            }
+        }
+    const char* Wb = reinterpret_cast<const char*>(W);
+    int koff[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) koff[c] = (c * 512 + lane * 8 < K ? c * 512 + lane * 8 : 0) * EB;
+    for (int n0 = wave * UNROLL; n0 < N; n0 += nwaves * UNROLL) {
+        uint4 wq[UNROLL][KC][EB / 2];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int n = n0 + u < N ? n0 + u : N - 1;   // clamped rows are computed and dropped
+            const char* wr = Wb + (size_t)n * Kpad * EB;
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int h = 0; h < EB / 2; ++h) wq[u][c][h] = *reinterpret_cast<const uint4*>(wr + koff[c] + 16 * h);
+        }
+        float acc[UNROLL][NB];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[u][b] = 0.f;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                float w[8];
+                if constexpr (WD == DT_F32) {
+                    const float* f0 = reinterpret_cast<const float*>(&wq[u][c][0]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = f0[j];
+                } else {
+                    unpack8<WD>(wq[u][c][0], w);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[u][b] = fmaf(w[j], av[b][c][j], acc[u][b]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float s = acc[u][b];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                if (lane == 0 && n0 + u < N) y[(size_t)b * ldy + n0 + u] = s + (bias ? bias[n0 + u] : 0.f);
+            }
+    }
+}
+
+template <int WD, int NB>
+static int gemv_dispatch(const float* a, int lda, const void* W, int Kpad, const float* bias, float* y, int ldy, int N, int K, int a_silu,
+                         hipStream_t s) {
+    const int kc = (K + 511) / 512;
+    int blocks = (N / 4 + 3) / 4;           // 4 rows per wave pass, 4 waves per block
+    if (blocks > 1024) blocks = 1024;       // 4 blocks per CU: every wave amortises its activation prologue over many rows
+    if (blocks < 1) blocks = 1;
+#define PD_GEMV(KC) hipLaunchKernelGGL((gemv_rows_kernel<WD, NB, KC>), dim3(blocks), dim3(256), 0, s, a, lda, W, Kpad, bias, y, ldy, N, K, a_silu)
+    switch (kc) {
+        case 1: PD_GEMV(1); break;
+        case 2: PD_GEMV(2); break;
+        case 3: PD_GEMV(3); break;
+        case 4: PD_GEMV(4); break;
+        default: return 1;
+    }
+#undef PD_GEMV
+    return hipGetLastError() != hipSuccess;
+}
+
+int launch_gemv(const float* a, int lda, const void* W, int w_dt, int Kpad, const float* bias, float* y, int ldy, int B, int N, int K,
+                int a_silu, hipStream_t s) {
+    if (B < 1 || B > 4 || K % 8 || K > 2048 || N < 1) return 1;
+#define PD_GEMV_B(WD)                                                                                              \
+    switch (B) {                                                                                                   \
+        case 1: return gemv_dispatch<WD, 1>(a, lda, W, Kpad, bias, y, ldy, N, K, a_silu, s);                       \
+        case 2: return gemv_dispatch<WD, 2>(a, lda, W, Kpad, bias, y, ldy, N, K, a_silu, s);                       \
+        case 3: return gemv_dispatch<WD, 3>(a, lda, W, Kpad, bias, y, ldy, N, K, a_silu, s);                       \
+        default: return gemv_dispatch<WD, 4>(a, lda, W, Kpad, bias, y, ldy, N, K, a_silu, s);                      \
+    }
+    if (w_dt == DT_F32) { PD_GEMV_B(DT_F32) }
+    if (w_dt == DT_F16) { PD_GEMV_B(DT_F16) }
+    PD_GEMV_B(DT_BF16)
+#undef PD_GEMV_B
+}

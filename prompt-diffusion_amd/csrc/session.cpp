@@ -735,6 +735,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "dense_k")) { e->opt_dense_k = (int)value; return 0; }
     if (!strcmp(key, "big_tile")) { e->opt_bigtile = value != 0; return 0; }
     if (!strcmp(key, "tile192")) { e->opt_tile192 = value != 0; return 0; }
+    if (!strcmp(key, "gemv")) { e->opt_gemv = value != 0; return 0; }
     if (!strcmp(key, "profile")) {
         (void)hipStreamSynchronize(e->stream);
         e->profiling = value != 0;

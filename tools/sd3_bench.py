@@ -51,12 +51,17 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--stream-f32", action="store_true")
+    ap.add_argument("--dump", default=None, help="with --profile: CSV of every profiled launch, and a per-shape table on stderr")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     a = ap.parse_args()
 
     import torch
     cfg = sd3.SD3Config(layers=a.layers, cn_layers=a.cn_layers, pos_embed_max_size=max(96, a.latent // 2))
     eng = sd3.SD3Engine(cfg, precision=a.precision, stream_f32=a.stream_f32)
     eng.init_random_weights(7)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.base.set_option(k, int(v))
     g = torch.Generator(device="cuda").manual_seed(0)
     f = lambda *s: torch.randn(*s, device="cuda", generator=g)
     B, H, S = a.batch, a.latent, a.ctx
@@ -92,6 +97,16 @@ def main():
             ms, n, flops = eng.base.profile_read(k)
             if n:
                 rec["by_class"][nm] = dict(ms_per_step=ms / a.steps, launches_per_step=n / a.steps, tflops_per_s=flops / ms / 1e9)
+        if a.dump:
+            eng.base.profile_dump(a.dump)
+            import collections, csv
+            agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+            for r in csv.DictReader(open(a.dump)):
+                k = (int(r["klass"]), int(r["M"]), int(r["N"]), int(r["K"]))
+                agg[k][0] += 1; agg[k][1] += float(r["ms"]); agg[k][2] += float(r["flops"])
+            for k, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print("klass %d M %6d N %6d K %5d: %5.1f launches/step %7.1f us  %6.2f ms/step  %6.0f TF/s" %
+                      (*k, n / a.steps, 1e3 * ms / n, ms / a.steps, fl / ms / 1e9), file=sys.stderr)
         eng.base.set_option("profile", 0)
     print(json.dumps(rec))
     eng.close()
