@@ -4,6 +4,7 @@
  * layouts, in the engine's precision mode, so tests/ can compare it with the oracle:
  *   pd_op_conv2d     nn.Conv2d 3x3/1x1 (stride 1/2, fused nearest-x2 upsample)   openaimodel.py:90-159,200-240
  *   pd_op_linear     nn.Linear / GEGLU / SiLU->Linear (emb_layers)                 attention.py:49-76, openaimodel.py:217-223
+ *   pd_op_linear_fp8 the e4m3 form of nn.Linear used by the SD3 path's sd3_fp8 option
  *   pd_op_groupnorm  GroupNorm32 (+SiLU)                                           util.py:217-219, attention.py:88-89
  *   pd_op_layernorm  nn.LayerNorm                                                  attention.py:263-265
  *   pd_op_attention  softmax(q k^T dh^-0.5) v, heads from the engine config        attention.py:171-193
@@ -18,6 +19,9 @@ int pd_op_conv2d(pd_engine* e, const float* x, const float* w, const float* bias
                  int W, int Cout, int k, int stride, int upsample, int act_silu, float scale, int stream_out, float* y);
 int pd_op_linear(pd_engine* e, const float* x, const float* w, const float* bias, int M, int K, int N, int geglu, int a_silu,
                  float* y);
+/* the SD3 path's PREC_FP8 linear layer (option sd3_fp8): e4m3 operands quantised on the device with one scale per row of x
+ * and of w, block-scaled MFMA, scales applied in the epilogue; act 0 or 4 (tanh-GELU).  2-byte engine modes only. */
+int pd_op_linear_fp8(pd_engine* e, const float* x, const float* w, const float* bias, int M, int K, int N, int act, float* y);
 int pd_op_groupnorm(pd_engine* e, const float* x, const float* gamma, const float* beta, int B, int C, int H, int W, float eps,
                     int silu, float* y);
 int pd_op_layernorm(pd_engine* e, const float* x, const float* gamma, const float* beta, int rows, int C, float* y);

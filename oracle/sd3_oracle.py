@@ -26,6 +26,28 @@ def linear(x, w, b=None):
     return y if b is None else y + b
 
 
+def quant_e4m3(x):
+    """Round-to-nearest-even onto the OCP e4m3fn grid (3 mantissa bits, normal range 2^-6 .. 448, subnormal step 2^-9),
+    saturating at +-448: what v_cvt_pk_fp8_f32 does to a clamped input."""
+    x = np.clip(np.asarray(x, np.float64), -448.0, 448.0)
+    e = np.floor(np.log2(np.maximum(np.abs(x), 2.0 ** -6)))
+    ulp = 2.0 ** (e - 3)
+    return (np.round(x / ulp) * ulp).astype(F32)
+
+
+def linear_fp8(x, w, b=None):
+    """The engine's PREC_FP8 linear layer: e4m3 operands with one scale per activation row and per weight row
+    (max |row| / 448), exact products, fp32 accumulation; scales applied to the sum."""
+    def rows(t):
+        amax = np.abs(t).max(-1, keepdims=True)
+        sc = np.where(amax > 0, amax * F32(1.0 / 448.0), F32(1.0)).astype(F32)
+        return quant_e4m3(t * (F32(1.0) / sc)), sc
+    xq, xs = rows(x)
+    wq, ws = rows(w)
+    y = (xq @ wq.T) * xs * ws[:, 0]
+    return (y if b is None else y + b).astype(F32)
+
+
 def silu(x):
     return x / (1.0 + np.exp(-x))
 
@@ -86,9 +108,12 @@ def attention(q, k, v, heads):
     return np.einsum("bhij,bhjd->bhid", a, sp(v)).transpose(0, 2, 1, 3).reshape(B, Nq, D).astype(F32)
 
 
-def joint_block(sd, pre, cfg, x, c, temb, context_pre_only):
-    """JointTransformerBlock: AdaLN-Zero on both streams, attention over [image ; context] tokens, gated residuals."""
+def joint_block(sd, pre, cfg, x, c, temb, context_pre_only, fp8=False):
+    """JointTransformerBlock: AdaLN-Zero on both streams, attention over [image ; context] tokens, gated residuals.
+    fp8: the engine's sd3_fp8 option -- the projections fed by an AdaLN output (q/k/v of both streams, ff / ff_context net.0)
+    take e4m3 operands (linear_fp8)."""
     P = lambda n: sd[pre + n]
+    qlinear = linear_fp8 if fp8 else linear
     e = silu(temb)
     m = linear(e, P("norm1.linear.weight"), P("norm1.linear.bias"))
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = np.split(m, 6, axis=-1)
@@ -101,24 +126,24 @@ def joint_block(sd, pre, cfg, x, c, temb, context_pre_only):
         c_sh_a, c_sc_a, c_g_a, c_sh_m, c_sc_m, c_g_m = np.split(mc, 6, axis=-1)
         cn = layer_norm_noaffine(c) * (1 + c_sc_a[:, None]) + c_sh_a[:, None]
     N = x.shape[1]
-    q = np.concatenate([linear(xn, P("attn.to_q.weight"), P("attn.to_q.bias")),
-                        linear(cn, P("attn.add_q_proj.weight"), P("attn.add_q_proj.bias"))], axis=1)
-    k = np.concatenate([linear(xn, P("attn.to_k.weight"), P("attn.to_k.bias")),
-                        linear(cn, P("attn.add_k_proj.weight"), P("attn.add_k_proj.bias"))], axis=1)
-    v = np.concatenate([linear(xn, P("attn.to_v.weight"), P("attn.to_v.bias")),
-                        linear(cn, P("attn.add_v_proj.weight"), P("attn.add_v_proj.bias"))], axis=1)
+    q = np.concatenate([qlinear(xn, P("attn.to_q.weight"), P("attn.to_q.bias")),
+                        qlinear(cn, P("attn.add_q_proj.weight"), P("attn.add_q_proj.bias"))], axis=1)
+    k = np.concatenate([qlinear(xn, P("attn.to_k.weight"), P("attn.to_k.bias")),
+                        qlinear(cn, P("attn.add_k_proj.weight"), P("attn.add_k_proj.bias"))], axis=1)
+    v = np.concatenate([qlinear(xn, P("attn.to_v.weight"), P("attn.to_v.bias")),
+                        qlinear(cn, P("attn.add_v_proj.weight"), P("attn.add_v_proj.bias"))], axis=1)
     o = attention(q, k, v, cfg.heads)
     ox = linear(o[:, :N], P("attn.to_out.0.weight"), P("attn.to_out.0.bias"))
     x = x + g_a[:, None] * ox
     xn2 = layer_norm_noaffine(x) * (1 + sc_m[:, None]) + sh_m[:, None]
-    ff = linear(gelu_tanh(linear(xn2, P("ff.net.0.proj.weight"), P("ff.net.0.proj.bias"))), P("ff.net.2.weight"), P("ff.net.2.bias"))
+    ff = linear(gelu_tanh(qlinear(xn2, P("ff.net.0.proj.weight"), P("ff.net.0.proj.bias"))), P("ff.net.2.weight"), P("ff.net.2.bias"))
     x = (x + g_m[:, None] * ff).astype(F32)
     if context_pre_only:
         return None, x
     oc = linear(o[:, N:], P("attn.to_add_out.weight"), P("attn.to_add_out.bias"))
     c = c + c_g_a[:, None] * oc
     cn2 = layer_norm_noaffine(c) * (1 + c_sc_m[:, None]) + c_sh_m[:, None]
-    ffc = linear(gelu_tanh(linear(cn2, P("ff_context.net.0.proj.weight"), P("ff_context.net.0.proj.bias"))),
+    ffc = linear(gelu_tanh(qlinear(cn2, P("ff_context.net.0.proj.weight"), P("ff_context.net.0.proj.bias"))),
                  P("ff_context.net.2.weight"), P("ff_context.net.2.bias"))
     c = (c + c_g_m[:, None] * ffc).astype(F32)
     return c, x
@@ -134,7 +159,7 @@ def time_text_embed(sd, pre, t, pooled):
     return (te + pe).astype(F32)
 
 
-def controlnet_forward(sd, cfg, x, t, ctx, pooled, cond, pair, scale=1.0, prefix="controlnet."):
+def controlnet_forward(sd, cfg, x, t, ctx, pooled, cond, pair, scale=1.0, prefix="controlnet.", fp8=False):
     """SD3PromptDiffusionModel.forward (promptdiffusioncontrolnet_sd3.py:431-476): list of cfg.cn_layers residuals."""
     P = lambda n: sd[prefix + n]
     B, C, H, W = x.shape
@@ -147,13 +172,13 @@ def controlnet_forward(sd, cfg, x, t, ctx, pooled, cond, pair, scale=1.0, prefix
     hs = (hs + patch_embed(cond, pi_w, pi_b, cfg.patch) + patch_embed(pair, pi_w, pi_b, cfg.patch)).astype(F32)   # :440
     res = []
     for i in range(cfg.cn_layers):
-        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, False)
+        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, False, fp8)
         res.append(hs)
     return [(linear(r, P(f"controlnet_blocks.{i}.weight"), P(f"controlnet_blocks.{i}.bias")) * F32(scale)).astype(F32)
             for i, r in enumerate(res)]
 
 
-def transformer_forward(sd, cfg, x, t, ctx, pooled, control=None, prefix="transformer."):
+def transformer_forward(sd, cfg, x, t, ctx, pooled, control=None, prefix="transformer.", fp8=False):
     """SD3Transformer2DModel.forward as the pipeline calls it (:1226-1234): velocity [B, C, H, W]."""
     P = lambda n: sd[prefix + n]
     B, C, H, W = x.shape
@@ -165,7 +190,7 @@ def transformer_forward(sd, cfg, x, t, ctx, pooled, control=None, prefix="transf
     interval = int(math.ceil(cfg.layers / len(control))) if control else 0
     for i in range(cfg.layers):
         last = i == cfg.layers - 1
-        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, last)
+        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, last, fp8)
         if control and not last:
             hs = (hs + control[i // interval]).astype(F32)
     m = linear(silu(temb), P("norm_out.linear.weight"), P("norm_out.linear.bias"))

@@ -443,6 +443,7 @@ int pd_engine::load(const char* name, const void* data, const int64_t* shape, in
     PD_TRY(upload_rows(m, p.row_off, src.data(), rows, p.conv));
     p.loaded = true;
     ln_dirty = true;
+    sd3_fp8_dirty = true;
     return 0;
 }
 
@@ -521,6 +522,7 @@ int pd_engine::init_random(uint64_t seed) {
     }
     HIP_OK(hipStreamSynchronize(stream));
     ln_dirty = true;
+    sd3_fp8_dirty = true;
     return 0;
 }
 
@@ -617,6 +619,11 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.gate = gx.gate; p.gate_stride = gx.gate_stride;
     p.c_sample_rows = gx.c_sample_rows; p.c_row_off = gx.c_row_off; p.vt_tok_off = gx.vt_tok_off;
     p.a_sample_rows = gx.a_sample_rows; p.a_row_off = gx.a_row_off;
+    const bool fp8 = in.dt == DT_FP8;
+    if (fp8) {   // e4m3 operands with per-row scales: the layer's quantised copy
+        if (!m.w8 || !gx.a_scale || m.taps != 1 || m.geglu) { pd_set_error("internal: fp8 GEMM without quantised weights / row scales"); return 1; }
+        p.W = m.w8; p.Kpad = m.Kpad8; p.w_scale = m.wscale; p.a_scale = gx.a_scale;
+    }
     const bool plain = !gx.gate && !gx.c_sample_rows && !gx.a_sample_rows;
     gx = GemmExtra{};
     // a handful of fp32 rows against a wide weight matrix: stream the weights once (gemm.hip's tiles would spend a 128-row
@@ -668,11 +675,11 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     if (!use_patch) {
         const size_t mk = arena.mark();
         const int tiles = gemm_tiles(p.M, m.N);
-        const int ktiles = m.Kpad / (128 / (int)dt_size(T));
+        const int ktiles = fp8 ? m.Kpad8 / 128 : m.Kpad / (128 / (int)dt_size(T));
         int splitk = 1;
         // linear layers with a short K and at least half a chip of tiles: one 8-wave block per CU instead of split-K
-        const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
-        if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
+        const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !fp8 && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
+        if (!fp8 && !dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
             splitk = (512 + tiles - 1) / tiles;
             if (splitk > ktiles / 8) splitk = ktiles / 8;
             if (splitk > opt_splitk_max) splitk = opt_splitk_max;
@@ -698,7 +705,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         // 128 x 160 tile on 8 waves at <= 128 VGPRs runs 2 blocks = 16 waves per CU (+0.6 % end-to-end, interleaved A/B)
         if (opt_short_k > 0 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_short_k) p.big_tile = 2;
         // widths that are multiples of 192 but not of 160 (MMDiT hidden size 1536 and its 3x / 4x): the 256 x 192 tile
-        if (opt_tile192 && !f32 && P != PREC_F16X2 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && m.N % 192 == 0 && m.N % 160 != 0 &&
+        if (opt_tile192 && !f32 && P != PREC_F16X2 && splitk == 1 && m.taps == 1 && (in.dt == T || fp8) && !m.geglu && m.N % 192 == 0 && m.N % 160 != 0 &&
             ((p.M + 255) / 256) * (m.N / 192) >= 192)
             p.big_tile = 4;
         if (P == PREC_F16X2 && m.geglu && p.big_tile == 3) p.big_tile = 1;   // the 256 x 320 GEGLU tile spills with the split-operand fragments
@@ -724,6 +731,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         pd_set_error("gemm: fp32 mode needs fp32 activations");
         return 1;
     }
+    const int prec = fp8 ? PREC_FP8 : P;
     ++launches;
     ProfRec rec{};
     if (profiling) {
@@ -738,7 +746,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     // second-generation (wave-specialised) patch kernel where it measures faster: many blocks per CU (its longer prologue
     // amortises) or the split-K 16x16 level; the 2-round 64x64 launches stay on the first generation (152 vs 142 us)
     const bool patch2 = use_patch && opt_patch2 && !f32 && !gn_coef && (patch_split > 1 || ptiles >= opt_patch2_tiles);
-    if (use_patch ? (patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream)) : launch_gemm(p, P, stream, mid)) {
+    if (use_patch ? (patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream)) : launch_gemm(p, prec, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;
     }

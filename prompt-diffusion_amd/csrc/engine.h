@@ -41,6 +41,10 @@ struct WMat {
     void* w_ln = nullptr;
     float* colsum = nullptr;
     float* bias_ln = nullptr;
+    // e4m3 copy with one scale per output row (pd_engine::sd3_quantize): the PREC_FP8 form of this layer
+    void* w8 = nullptr;
+    float* wscale = nullptr;
+    int Kpad8 = 0;
 };
 
 // LayerNorm statistics handed from the GEMM that writes a residual-stream tensor to the GEMM that consumes its LayerNorm
@@ -333,7 +337,10 @@ struct pd_engine {
     int sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt);
     int sd3_forward(const Sd3Io& io, float* v_out_dev, int control_index, float* control_out_dev);
     // one-shot extras of the next gemm() call (MMDiT: gated residual, joint-buffer row remap)
-    struct GemmExtra { const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0, a_sample_rows = 0, a_row_off = 0; } gx;
+    struct GemmExtra { const float* a_scale = nullptr; const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0, a_sample_rows = 0, a_row_off = 0; } gx;
+    bool opt_sd3_fp8 = false;  // SD3 path: QKV and feed-forward-in projections in PREC_FP8 (e4m3 operands, per-row scales)
+    bool sd3_fp8_dirty = true;
+    int sd3_quantize();        // (re)builds the e4m3 weights of those layers after a weight change
     bool opt_gemv = true;     // Linear over <= 4 fp32 rows with a wide output (MMDiT modulation): weight-streaming kernel instead of a GEMM tile
 
     // weights

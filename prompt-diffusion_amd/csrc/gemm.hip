@@ -44,17 +44,17 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     constexpr bool F32 = prec_f32_storage(P);
     // register prefetch depth: two K steps ahead (two named staging sets) unless the fp32->bf16 staging
     // path already doubles the A registers
-    constexpr int DEPTH = (AF32 || BN > 192 || (BM == 128 && WM * WN == 8) || P == PREC_F16X2) ? 1 : 2;   // the 16-waves-per-CU shape has 128 VGPRs per wave
+    constexpr int DEPTH = (AF32 || BN > 192 || (BM == 128 && WM * WN == 8) || P == PREC_F16X2 || P == PREC_FP8) ? 1 : 2;   // the 16-waves-per-CU shape has 128 VGPRs per wave
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int A_ITERS = BM * 8 / NTHREADS;                   // 16-byte chunks per thread per K step
     constexpr int B_ITERS = (BN * 8 + NTHREADS - 1) / NTHREADS;  // last one masked when it does not divide
     constexpr int ROWS_PER_IT = NTHREADS / 8;
-    constexpr int EB = F32 ? 4 : 2;
+    constexpr int EB = F32 ? 4 : (P == PREC_FP8 ? 1 : 2);
     constexpr int VEC = 16 / EB;    // elements per 16-byte chunk
     constexpr int BKE = BKB / EB;   // elements of K per step
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MT = WTM / 16, NT = WTN / 16;
-    constexpr int AEB = (F32 || AF32) ? 4 : 2;  // bytes per element of the A source
+    constexpr int AEB = (F32 || AF32) ? 4 : EB;  // bytes per element of the A source
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -240,6 +240,22 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const char* sa = smem + buf * (BM + BN) * BKB;
         const char* sb = sa + BM * BKB;
+        if constexpr (P == PREC_FP8) {   // one K = 128 block-scaled MFMA per accumulator and K step
+            // fragments are 32 bytes per lane here: all of A's stay live, the weights' are read one column block at a time
+            i32x8 af[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                af[m] = prep_f8(*reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, fq)),
+                                *reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, 4 + fq)));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const i32x8 wf = prep_f8(*reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, fq)),
+                                         *reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, 4 + fq)));
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mma_f8(wf, af[m], acc[n][m]);
+            }
+            return;
+        }
         if constexpr (P == PREC_F16X2) {   // both half-steps at once: 3 MFMAs per accumulator and K step (pd_mma.h)
             FragX2 af[MT], wf[NT];
 #pragma unroll
@@ -256,6 +272,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
                 for (int m = 0; m < MT; ++m) mma_x2(wf[n], af[m], acc[n][m]);
             return;
         }
+        if constexpr (P != PREC_FP8 && P != PREC_F16X2) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             typename Frag<P>::A af[MT];
@@ -268,6 +285,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) mma<P>(wf[n], af[m], acc[n][m]);
+        }
         }
     };
     using S0 = std::integral_constant<int, 0>;
@@ -491,6 +509,14 @@ int launch_splitk_finalize(const GemmParams& p, hipStream_t s) {
 int gemm_tiles(int M, int N) { return ((M + 127) / 128) * ((N + 159) / 160); }
 
 namespace {
+// PREC_FP8: linear layers with the MMDiT epilogue only (the SD3 path's QKV and feed-forward-in projections)
+int launch_fp8(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
+    if (p.taps != 1 || p.a_dt != DT_FP8 || !p.a_scale || !p.w_scale || p.act == 2 || p.splitk > 1 || p.Kpad % 128) return 1;
+    if (p.big_tile == 4) return launch_one<PREC_FP8, 256, 192, 4, 2, false, false, false, true>(p, s, mid);
+    if (p.big_tile == 1 || p.big_tile == 3) return launch_one<PREC_FP8, 256, 160, 4, 2, false, false, false, true>(p, s, mid);
+    return launch_one<PREC_FP8, 128, 160, 2, 2, false, false, false, true>(p, s, mid);
+}
+
 template <int P>
 int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr bool F = prec_f32_storage(P);
@@ -546,6 +572,7 @@ int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
 int launch_gemm(const GemmParams& p, int prec, hipStream_t s, hipEvent_t mid) {
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.splitk > 1 && (p.act == 2 || p.vt_begin < p.N || !p.slab || p.N % 4)) return 1;
+    if (prec == PREC_FP8) return launch_fp8(p, s, mid);
     if (prec_f32_storage(prec) ? p.a_dt != DT_F32 : (p.a_dt != DT_F32 && p.a_dt != prec)) return 1;   // operand type must match the mode
     switch (prec) {
         case DT_F32: return launch_prec<DT_F32>(p, s, mid);

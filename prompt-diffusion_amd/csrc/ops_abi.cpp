@@ -104,6 +104,45 @@ int pd_op_linear(pd_engine* e, const float* x, const float* w, const float* bias
     return 0;
 }
 
+// y[M,N] = (e4m3(x / sx) @ e4m3(w / sw)^T) * sx * sw + b with per-row scales (max |row| / 448): the PREC_FP8 linear layer of
+// the SD3 path (option sd3_fp8) on host fp32 arrays; act 4: tanh-GELU epilogue.  2-byte engine modes only.
+int pd_op_linear_fp8(pd_engine* e, const float* x, const float* w, const float* bias, int M, int K, int N, int act, float* y) {
+    if (!e || !x || !w || !y) { pd_set_error("null argument"); return 1; }
+    if (e->f32) { pd_set_error("pd_op_linear_fp8: 2-byte engine modes only"); return 1; }
+    if (K % 8 || (act != 0 && act != 4)) { pd_set_error("pd_op_linear_fp8: K must be a multiple of 8, act 0 or 4"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    TempMat guard(e);
+    WMat m;
+    e->make_mat(m, N, K, 1, K, true);
+    if (!m.w) { pd_set_error("allocation failed"); return 1; }
+    if (bias) PD_TRY(e->upload_vec(m.bias, bias, N, false, 0));
+    m.Kpad8 = round_up(K, 128);
+    DevBuf w32((size_t)N * K * 4), w8((size_t)m.N * m.Kpad8), ws((size_t)(m.N + 4) * 4), x32((size_t)M * K * 4), x8((size_t)M * m.Kpad8),
+        xs((size_t)M * 4 + 16), out((size_t)M * round_up(N, 4) * 4);
+    if (!w32.p || !w8.p || !ws.p || !x32.p || !x8.p || !xs.p || !out.p) { pd_set_error("allocation failed"); return 1; }
+    HIP_OK(hipMemset(w8.p, 0, (size_t)m.N * m.Kpad8));
+    HIP_OK(hipMemcpy(w32.p, w, (size_t)N * K * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(x32.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipDeviceSynchronize());
+    if (launch_quant_rows(w32.p, DT_F32, K, w8.p, m.Kpad8, reinterpret_cast<float*>(ws.p), N, K, e->stream) ||
+        launch_quant_rows(x32.p, DT_F32, K, x8.p, m.Kpad8, reinterpret_cast<float*>(xs.p), M, K, e->stream)) {
+        pd_set_error("quantisation launch failed");
+        return 1;
+    }
+    m.w8 = w8.p; m.wscale = reinterpret_cast<float*>(ws.p);
+    m.cin_pad = m.Kpad8;   // the activation rows are padded to the fp8 K step
+    Act a, o;
+    a.p = x8.p; a.B = M; a.H = 1; a.W = 1; a.C = m.Kpad8; a.dt = DT_FP8;
+    o.p = out.p; o.B = M; o.H = 1; o.W = 1; o.C = round_up(N, 4); o.dt = DT_F32;
+    e->gx.a_scale = reinterpret_cast<float*>(xs.p);
+    PD_TRY(e->gemm(m, a, o, 1, 0, act, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    std::vector<float> host((size_t)M * o.C);
+    HIP_OK(hipMemcpy(host.data(), out.p, host.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < M; ++i) memcpy(y + (size_t)i * N, host.data() + (size_t)i * o.C, (size_t)N * 4);
+    return 0;
+}
+
 int pd_op_groupnorm(pd_engine* e, const float* x, const float* gamma, const float* beta, int B, int C, int H, int W, float eps,
                     int silu, float* y) {
     if (!e || !x || !gamma || !beta || !y) { pd_set_error("null argument"); return 1; }

@@ -6,12 +6,16 @@
 
 // Storage / MFMA operand types.  DT_BF16 and DT_F16 share one byte-level data path (2-byte elements); the engine's
 // compute type T is one of the three and selects the MFMA instruction and the converts.
-enum PdDType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
-static inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+enum PdDType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2, DT_FP8 = 4 };   // DT_FP8: OCP e4m3fn bytes + one fp32 scale per row
+static inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : dt == DT_FP8 ? 1 : 2; }
 // MFMA precision codes handed to the contraction launchers: the operand PdDType, or PREC_F16X2 -- fp32 storage like
 // DT_F32, but every operand is split into fp16 hi + lo halves in registers and the product runs as two fp16 MFMAs
 // (all four hi/lo cross terms): ~22-bit operands at a quarter of the fp16 MFMA rate, 4x the fp32 MFMA rate.
 constexpr int PREC_F16X2 = 3;
+// PREC_FP8 (== DT_FP8): both operands e4m3 with per-row scales (A: per token, W: per output channel), one
+// v_mfma_scale_f32_16x16x128_f8f6f4 (block scales 1.0) per accumulator and 128-byte K step -- twice the f16 MFMA rate at
+// half the LDS bytes per FLOP; the scales multiply the accumulator in the epilogue.  Linear layers of the SD3 path only.
+constexpr int PREC_FP8 = 4;
 constexpr bool prec_f32_storage(int P) { return P == DT_F32 || P == PREC_F16X2; }
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -191,6 +195,9 @@ struct GemmParams {
     // ... and of the A rows (linear, MM instantiations): row = sample * a_sample_rows + a_row_off + tok -- one token stream
     // read out of a joint buffer (a_sample_rows = 0: row = m)
     int a_sample_rows, a_row_off;
+    // PREC_FP8: acc * a_scale[m] * w_scale[n] before everything else in the epilogue
+    const float* a_scale;
+    const float* w_scale;
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
@@ -207,6 +214,9 @@ struct AttnParams {
 };
 
 int launch_gemm(const GemmParams& p, int prec, hipStream_t s, hipEvent_t mid = nullptr);   // prec: the compute type (DT_*)
+// fp8 (e4m3) rows with one scale per row: dst[r][k] = e4m3(src[r][k] / scale[r]), scale[r] = max_k |src[r][k]| / 448 (weights of
+// the SD3 linear layers that run in PREC_FP8); src in dtype src_dt with row stride src_ld, dst row stride dst_ld >= K (pad zeroed)
+int launch_quant_rows(const void* src, int src_dt, int src_ld, void* dst, int dst_ld, float* scale, int rows, int K, hipStream_t s);
 // y[b][n] = bias[n] + sum_k W[n][k] * f(a[b][k]) for B <= 4 fp32 rows (f = SiLU when a_silu): the weight-streaming form of
 // a Linear over a handful of rows (MMDiT modulation vectors); w_dt: DT_F32 / DT_F16 / DT_BF16, K % 8 == 0, K <= 2048
 int launch_gemv(const float* a, int lda, const void* W, int w_dt, int Kpad, const float* bias, float* y, int ldy, int B, int N, int K,
@@ -250,8 +260,9 @@ int launch_cfg_ddim(const void* eps, int eps_dt, int eps_C, float* x_state, floa
                     float temperature, int do_update, hipStream_t s);
 int launch_fill_random(void* p, int dt, long long n, float scale, float shift, uint64_t seed, hipStream_t s);
 // sd3_kernels.hip: element-wise pieces of the MMDiT path
+// y_dt == DT_FP8: y holds e4m3 bytes and y_scale[row] the row's scale (max |value| / 448)
 int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, int mod_stride, int shift_off, int scale_off, int rows,
-                 int rows_per_sample, int C, float eps, hipStream_t s);
+                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale = nullptr);
 int launch_patchify(const float* nchw, void* out, int out_dt, int B, int C, int H, int W, int patch, int Cpad, int Kpad, hipStream_t s);
 int launch_pos_crop(const float* table, float* out, int B, int h, int w, int max_size, int D, hipStream_t s);
 int launch_unpatchify(const void* in, int in_dt, int ld, float* nchw, int B, int C, int h, int w, int patch, hipStream_t s);

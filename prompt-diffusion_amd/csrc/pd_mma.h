@@ -88,6 +88,18 @@ __device__ __forceinline__ void mma_x2(const FragX2& w, const FragX2& a, f32x4& 
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w.lo), __builtin_bit_cast(f16x8, a.hi), acc, 0, 0, 0);
 }
 
+// PREC_FP8 over a whole 128-byte K step: lane (fr, fq) holds 32 e4m3 values of its row -- LDS chunks fq and 4 + fq, the same
+// k permutation on both operands -- and one block-scaled MFMA (all block scales 2^0) sums the 128 products per accumulator
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ i32x8 prep_f8(const uint4& c0, const uint4& c1) {
+    i32x8 r;
+    r[0] = c0.x; r[1] = c0.y; r[2] = c0.z; r[3] = c0.w; r[4] = c1.x; r[5] = c1.y; r[6] = c1.z; r[7] = c1.w;
+    return r;
+}
+__device__ __forceinline__ void mma_f8(const i32x8& w, const i32x8& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, acc, 0 /*A: e4m3*/, 0 /*B: e4m3*/, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
 // the same from two raw 16-byte fragments (converts per call in PREC_F16X2: attention only)
 template <int P>
 __device__ __forceinline__ void mma_raw(const uint4& w, const uint4& a, f32x4& acc) {
@@ -139,6 +151,14 @@ __device__ __forceinline__ f32x4 ln_apply4(const GemmParams& p, int gn, f32x4 v,
 template <bool MM = false>
 __device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, int sample, int tok, f32x4 v, float ln_mean = 0.f,
                                            float ln_rstd = 0.f) {
+    if constexpr (MM) {
+        if (p.a_scale) {   // PREC_FP8: per-token x per-channel operand scales
+            const f32x4 ws = *reinterpret_cast<const f32x4*>(p.w_scale + gn);
+            const float as = p.a_scale[gm];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= as * ws[j];
+        }
+    }
     if (p.ln_stats) v = ln_apply4(p, gn, v, ln_mean, ln_rstd);
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + gn);
     if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (size_t)sample * p.rowvec_stride + gn);

@@ -184,27 +184,33 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     const float* mod = reinterpret_cast<const float*>(modbuf.p);
     const int ms = modbuf.C, vt_ld = vt.C;
     const size_t mk = arena.mark();
-    auto adaln = [&](const Act& in, Act& out, int shift_off, int scale_off) -> int {
+    // option sd3_fp8 (2-byte modes): the AdaLN outputs feeding the QKV and feed-forward-in projections are written as e4m3
+    // with one scale per token, and those GEMMs run in PREC_FP8 against the layers' quantised weights
+    const bool f8 = opt_sd3_fp8 && !f32;
+    const int NT = f8 ? DT_FP8 : T;
+    auto adaln = [&](const Act& in, Act& out, int shift_off, int scale_off, float* row_scale) -> int {
         if (arena.dry) return 0;
         PD_TRY(check_arena());
         ++launches;
-        if (launch_adaln(in.p, in.dt, out.p, out.dt, mod, ms, shift_off, scale_off, (int)in.rows(), in.H, D, 1e-6f, stream)) {
+        if (launch_adaln(in.p, in.dt, out.p, out.dt, mod, ms, shift_off, scale_off, (int)in.rows(), in.H, D, 1e-6f, stream, row_scale)) {
             pd_set_error("sd3: AdaLN launch failed (C=%d)", D);
             return 1;
         }
         return 0;
     };
-    Act xn = new_act(B, N, 1, D, T), cn = new_act(B, Sx, 1, D, T);
-    PD_TRY(adaln(x, xn, b.mod_off, b.mod_off + D));                         // (shift_msa, scale_msa, gate_msa, shift_mlp, ...)
-    if (b.pre_only) PD_TRY(adaln(c, cn, b.mod_c_off + D, b.mod_c_off));     // AdaLayerNormContinuous: (scale, shift)
-    else PD_TRY(adaln(c, cn, b.mod_c_off, b.mod_c_off + D));
+    auto scales = [&](int rows) { return f8 ? reinterpret_cast<float*>(arena.alloc((size_t)rows * sizeof(float))) : nullptr; };
+    Act xn = new_act(B, N, 1, D, NT), cn = new_act(B, Sx, 1, D, NT);
+    float *xs = scales(B * N), *cs = scales(B * Sx);
+    PD_TRY(adaln(x, xn, b.mod_off, b.mod_off + D, xs));                         // (shift_msa, scale_msa, gate_msa, shift_mlp, ...)
+    if (b.pre_only) PD_TRY(adaln(c, cn, b.mod_c_off + D, b.mod_c_off, cs));     // AdaLayerNormContinuous: (scale, shift)
+    else PD_TRY(adaln(c, cn, b.mod_c_off, b.mod_c_off + D, cs));
     // both QKV GEMMs store straight into the joint buffers
     {
         Act o = qk; o.H = N;
-        gx.c_sample_rows = Nt; gx.c_row_off = 0; gx.vt_tok_off = 0;
+        gx.c_sample_rows = Nt; gx.c_row_off = 0; gx.vt_tok_off = 0; gx.a_scale = xs;
         PD_TRY(gemm(b.qkv, xn, o, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * D, vt_ld));
         o.H = Sx;
-        gx.c_sample_rows = Nt; gx.c_row_off = N; gx.vt_tok_off = N;
+        gx.c_sample_rows = Nt; gx.c_row_off = N; gx.vt_tok_off = N; gx.a_scale = cs;
         PD_TRY(gemm(b.qkv_c, cn, o, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * D, vt_ld));
     }
     // ONE attention launch over the joint sequence (image queries only in the context_pre_only block); the out-projections
@@ -223,23 +229,53 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     arena.release(mk);
     // feed-forward of each stream
     {
-        Act n2 = new_act(B, N, 1, D, T);
-        PD_TRY(adaln(x, n2, b.mod_off + 3 * D, b.mod_off + 4 * D));
+        Act n2 = new_act(B, N, 1, D, NT);
+        float* ns = scales(B * N);
+        PD_TRY(adaln(x, n2, b.mod_off + 3 * D, b.mod_off + 4 * D, ns));
         Act f = new_act(B, N, 1, 4 * D, T);
+        gx.a_scale = ns;
         PD_TRY(gemm(b.ff1, n2, f, 1, 0, /*tanh-GELU*/ 4, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
         gx.gate = mod + b.mod_off + 5 * D; gx.gate_stride = ms;
         PD_TRY(gemm(b.ff2, f, x, 1, 0, 0, 1.f, &x, nullptr, 0, false, nullptr, 0, 0));
         arena.release(mk);
     }
     if (!b.pre_only) {
-        Act n2 = new_act(B, Sx, 1, D, T);
-        PD_TRY(adaln(c, n2, b.mod_c_off + 3 * D, b.mod_c_off + 4 * D));
+        Act n2 = new_act(B, Sx, 1, D, NT);
+        float* ns = scales(B * Sx);
+        PD_TRY(adaln(c, n2, b.mod_c_off + 3 * D, b.mod_c_off + 4 * D, ns));
         Act f = new_act(B, Sx, 1, 4 * D, T);
+        gx.a_scale = ns;
         PD_TRY(gemm(b.ffc1, n2, f, 1, 0, 4, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
         gx.gate = mod + b.mod_c_off + 5 * D; gx.gate_stride = ms;
         PD_TRY(gemm(b.ffc2, f, c, 1, 0, 0, 1.f, &c, nullptr, 0, false, nullptr, 0, 0));
         arena.release(mk);
     }
+    return 0;
+}
+
+// e4m3 copies (one scale per output row) of the layers option sd3_fp8 runs in PREC_FP8
+int pd_engine::sd3_quantize() {
+    if (!opt_sd3_fp8 || f32 || !sd3_fp8_dirty) return 0;
+    for (Sd3NetW* net : {&sd3_tr, &sd3_cn}) {
+        if (!net->built) continue;
+        for (Sd3BlockW& b : net->blocks) {
+            WMat* mats[4] = {&b.qkv, &b.qkv_c, &b.ff1, b.pre_only ? nullptr : &b.ffc1};
+            for (WMat* m : mats) {
+                if (!m) continue;
+                if (!m->w8) {
+                    m->Kpad8 = round_up(m->K, 128);
+                    m->w8 = dmalloc((size_t)m->N * m->Kpad8);
+                    m->wscale = reinterpret_cast<float*>(dmalloc((size_t)(m->N + 4) * sizeof(float)));
+                    if (!m->w8 || !m->wscale) { pd_set_error("allocation of fp8 weights failed"); return 1; }
+                }
+                if (launch_quant_rows(m->w, T, m->Kpad, m->w8, m->Kpad8, m->wscale, m->N, m->K, stream)) {
+                    pd_set_error("fp8 weight quantisation launch failed");
+                    return 1;
+                }
+            }
+        }
+    }
+    sd3_fp8_dirty = false;
     return 0;
 }
 
@@ -401,6 +437,7 @@ int sd3_check(pd_engine* e, const pd_sd3_args* a, bool need_cond) {
 int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, float guidance, const float* step_scales,
             int control_index, float* out) {
     HIP_OK(hipSetDevice(e->device));
+    PD_TRY(e->sd3_quantize());
     const bool loop = steps >= 0;
     const bool cfg = loop && guidance > 1.0f;
     const int B = a->batch, Bf = cfg ? 2 * B : B;

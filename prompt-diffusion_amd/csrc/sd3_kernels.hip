@@ -2,13 +2,16 @@
 // All HBM-bound single passes; the contractions run on the igemm / attention kernels of the UNet path.
 #include "pd_common.h"
 
+// v_cvt_pk_fp8_f32 turns |x| > 448 into NaN: saturate first (the scales map the row maximum onto 448, so this only absorbs rounding)
+__device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }
+
 // AdaLayerNormZero / AdaLayerNormContinuous body: y = LN(x) (no affine, eps) * (1 + scale[b]) + shift[b].
 // One wave per row, the row held in registers between the two passes; C <= 2048, C % 4 == 0.
 // mod: fp32 [B][mod_stride] (output of the modulation GEMM), the chunk of this norm at shift_off / scale_off.
 template <int XD, int YD>
 __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ mod,
                                                      int mod_stride, int shift_off, int scale_off, int rows, int rows_per_sample,
-                                                     int C, float eps) {
+                                                     int C, float eps, float* __restrict__ y_scale) {
     constexpr int MAXV = 8;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, 
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = 1.0f / sqrtf(q / (float)C + eps);
     const float* mrow = mod + (size_t)(row / rows_per_sample) * mod_stride;
+    float amax = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         const int vi = lane + 64 * k;
@@ -46,23 +50,48 @@ __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, 
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = fmaf((v[k][j] - mean) * rstd, 1.0f + sc[j], sh[j]);
-            store4(y, (size_t)row * C + (size_t)vi * 4, YD, o);
+            if constexpr (YD == DT_FP8) {
+                v[k] = o;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+            } else {
+                store4(y, (size_t)row * C + (size_t)vi * 4, YD, o);
+            }
+        }
+    }
+    if constexpr (YD == DT_FP8) {   // e4m3 bytes with the row's scale: value = byte * scale, |byte| <= 448
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+        const float inv = 1.0f / scale;
+        if (lane == 0) y_scale[row] = scale;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int vi = lane + 64 * k;
+            if (vi < nv) {
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[k][0] * inv), clamp448(v[k][1] * inv), 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[k][2] * inv), clamp448(v[k][3] * inv), w, true);
+                reinterpret_cast<int*>(y)[(size_t)row * (C / 4) + vi] = w;
+            }
         }
     }
 }
 
 int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, int mod_stride, int shift_off, int scale_off, int rows,
-                 int rows_per_sample, int C, float eps, hipStream_t s) {
+                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale) {
     if (C % 4 || C > 2048 || rows < 1 || rows_per_sample < 1 || (mod_stride | shift_off | scale_off) % 4) return 1;
+    if (y_dt == DT_FP8 && !y_scale) return 1;
     const dim3 grid((rows + 3) / 4);
 #define PD_ADALN(XD, YD)                                                                                                       \
     hipLaunchKernelGGL((adaln_kernel<XD, YD>), grid, dim3(256), 0, s, x, y, mod, mod_stride, shift_off, scale_off, rows, \
-                       rows_per_sample, C, eps)
+                       rows_per_sample, C, eps, y_scale)
     if (x_dt == DT_F32 && y_dt == DT_F32) PD_ADALN(DT_F32, DT_F32);
     else if (x_dt == DT_F32 && y_dt == DT_F16) PD_ADALN(DT_F32, DT_F16);
     else if (x_dt == DT_F32 && y_dt == DT_BF16) PD_ADALN(DT_F32, DT_BF16);
     else if (x_dt == DT_F16 && y_dt == DT_F16) PD_ADALN(DT_F16, DT_F16);
     else if (x_dt == DT_BF16 && y_dt == DT_BF16) PD_ADALN(DT_BF16, DT_BF16);
+    else if (x_dt == DT_F32 && y_dt == DT_FP8) PD_ADALN(DT_F32, DT_FP8);
+    else if (x_dt == DT_F16 && y_dt == DT_FP8) PD_ADALN(DT_F16, DT_FP8);
+    else if (x_dt == DT_BF16 && y_dt == DT_FP8) PD_ADALN(DT_BF16, DT_FP8);
     else return 1;
 #undef PD_ADALN
     return hipGetLastError() != hipSuccess;
@@ -274,4 +303,43 @@ int launch_gemv(const float* a, int lda, const void* W, int w_dt, int Kpad, cons
     if (w_dt == DT_F16) { PD_GEMV_B(DT_F16) }
     PD_GEMV_B(DT_BF16)
 #undef PD_GEMV_B
+}
+
+// Weight rows -> e4m3 with one scale per row (one wave per row, two passes over the row: it is read from L2 the second time)
+template <int XD>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const void* __restrict__ src, int src_ld, uint8_t* __restrict__ dst, int dst_ld,
+                                                          float* __restrict__ scale, int rows, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float amax = 0.f;
+    for (int v = lane; v < K / 4; v += 64) {
+        const f32x4 t = load4(src, (size_t)row * src_ld + (size_t)v * 4, XD);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    for (int v = lane; v < dst_ld / 4; v += 64) {
+        int w = 0;
+        if (v < K / 4) {
+            const f32x4 t = load4(src, (size_t)row * src_ld + (size_t)v * 4, XD);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(t[0] * inv), clamp448(t[1] * inv), 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(t[2] * inv), clamp448(t[3] * inv), w, true);
+        }
+        reinterpret_cast<int*>(dst)[(size_t)row * (dst_ld / 4) + v] = w;
+    }
+}
+
+int launch_quant_rows(const void* src, int src_dt, int src_ld, void* dst, int dst_ld, float* scale, int rows, int K, hipStream_t s) {
+    if (rows < 1 || K % 4 || dst_ld % 4 || dst_ld < K || src_ld % 4) return 1;
+    const dim3 grid((rows + 3) / 4);
+    uint8_t* d = reinterpret_cast<uint8_t*>(dst);
+    if (src_dt == DT_F32) hipLaunchKernelGGL((quant_rows_kernel<DT_F32>), grid, dim3(256), 0, s, src, src_ld, d, dst_ld, scale, rows, K);
+    else if (src_dt == DT_F16) hipLaunchKernelGGL((quant_rows_kernel<DT_F16>), grid, dim3(256), 0, s, src, src_ld, d, dst_ld, scale, rows, K);
+    else if (src_dt == DT_BF16) hipLaunchKernelGGL((quant_rows_kernel<DT_BF16>), grid, dim3(256), 0, s, src, src_ld, d, dst_ld, scale, rows, K);
+    else return 1;
+    return hipGetLastError() != hipSuccess;
 }

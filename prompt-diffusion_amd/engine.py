@@ -131,6 +131,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     fp = C.c_void_p
     lib.pd_op_conv2d.argtypes = [C.c_void_p, fp, fp, fp, fp] + [C.c_int] * 9 + [C.c_float, C.c_int, fp]
     lib.pd_op_linear.argtypes = [C.c_void_p, fp, fp, fp] + [C.c_int] * 5 + [fp]
+    lib.pd_op_linear_fp8.argtypes = [C.c_void_p, fp, fp, fp] + [C.c_int] * 4 + [fp]
     lib.pd_op_groupnorm.argtypes = [C.c_void_p, fp, fp, fp] + [C.c_int] * 4 + [C.c_float, C.c_int, fp]
     lib.pd_op_layernorm.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_int, fp]
     lib.pd_op_attention.argtypes = [C.c_void_p, fp, fp, fp] + [C.c_int] * 4 + [fp]
@@ -146,7 +147,7 @@ EXPORTS = [
     "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_wait_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_encode_ex", "pd_text_weights_missing",
     "pd_profile_read", "pd_profile_dump",
     "pd_sd3_configure", "pd_sd3_weights_missing", "pd_sd3_forward", "pd_sd3_control", "pd_sd3_sample",
-    "pd_op_conv2d", "pd_op_linear", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention",
+    "pd_op_conv2d", "pd_op_linear", "pd_op_linear_fp8", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention",
 ]
 
 
@@ -534,6 +535,17 @@ class Engine:
         bb = None if b is None else np.ascontiguousarray(b, np.float32)
         self._check(self.lib.pd_op_linear(self._h, x.ctypes.data, w.ctypes.data, None if bb is None else bb.ctypes.data,
                                           M, K, N, int(geglu), int(a_silu), y.ctypes.data))
+        return y
+
+    def op_linear_fp8(self, x, w, b=None, gelu_tanh=False):
+        """The SD3 path's e4m3 linear layer (per-row scales of x and w) on host arrays."""
+        x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+        M, K = x.shape
+        N = w.shape[0]
+        y = np.empty((M, N), np.float32)
+        bb = None if b is None else np.ascontiguousarray(b, np.float32)
+        self._check(self.lib.pd_op_linear_fp8(self._h, x.ctypes.data, w.ctypes.data, None if bb is None else bb.ctypes.data, M, K, N,
+                                              4 if gelu_tanh else 0, y.ctypes.data))
         return y
 
     def op_groupnorm(self, x, gamma, beta, eps=1e-5, silu=False):

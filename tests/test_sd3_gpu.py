@@ -163,3 +163,44 @@ def test_errors(sd):
                              steps=2, cfg_scale=7.5)
     assert np.isfinite(out).all()
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------ sd3_fp8 option
+@pytest.mark.parametrize("M,K,N", [(300, 128, 192), (77, 200, 160), (1024, 1536, 384), (6144 + 5, 256, 1536)])
+def test_fp8_linear_kernel_against_emulation(M, K, N):
+    """The PREC_FP8 GEMM (block-scaled K = 128 MFMA, per-row operand scales in the epilogue) against the oracle's exact
+    emulation of the same quantisation: identical e4m3 operands, so only the fp32 summation order differs.  Covers K that is
+    not a multiple of 128 (zero-padded step), ragged M, and the 256 x 192 tile."""
+    rng = np.random.default_rng(M + K)
+    x = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-3, 3, (M, 1)))).astype(np.float32)   # rows of very different scale
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) * 0.1
+    e = E.Engine(__import__("prompt_diffusion_amd.weights", fromlist=["TINY"]).TINY, precision="f16")
+    ref = O.linear_fp8(x, w, b)
+    # (products of e4m3 values are exact; the MFMA sums 128 of them per step in fp32 -- heavy cancellation at these scales)
+    assert relerr(e.op_linear_fp8(x, w, b), ref) < 1e-4
+    assert relerr(e.op_linear_fp8(x, w, None, gelu_tanh=True), O.gelu_tanh(O.linear_fp8(x, w))) < 1e-4
+    assert 5e-3 < relerr(ref, O.linear(x, w, b)) < 1e-1           # what e4m3 operands cost one layer
+    e.close()
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_fp8_option_against_emulating_oracle(sd, prec):
+    """Whole evaluation with option sd3_fp8: against the oracle that emulates the e4m3 operands of the same layers the error
+    is the 2-byte mode's own (plus rounding-boundary flips of single e4m3 values); against the unquantised oracle it is what
+    fp8 operands cost this (random-weight) network."""
+    e = sd3.SD3Engine(CFG, precision=prec, fp8=True)
+    e.load_state_dict(sd)
+    i = inputs(2, 8, 12, 9, seed=71)
+    zero = np.zeros_like(i["pooled"])
+    got = e.forward(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 0.8)
+    ctl8 = O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], zero, i["cond"], i["pair"], 0.8, fp8=True)
+    ref8 = O.transformer_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], ctl8, fp8=True)
+    ctl = O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], zero, i["cond"], i["pair"], 0.8)
+    ref = O.transformer_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], ctl)
+    e8, e32 = relerr(got, ref8), relerr(got, ref)
+    print("%s + fp8: vs emulating oracle %.2e, vs fp32 oracle %.2e (oracle fp8 vs fp32 %.2e)" % (prec, e8, e32, relerr(ref8, ref)))
+    assert e8 < 2 * TOL[prec] and e32 < 1.5e-1
+    with pytest.raises(ValueError):
+        sd3.SD3Engine(CFG, precision="f32", fp8=True)
+    e.close()

@@ -51,13 +51,14 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--stream-f32", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="e4m3 operands for the AdaLN-fed projections (BASELINE config #5)")
     ap.add_argument("--dump", default=None, help="with --profile: CSV of every profiled launch, and a per-shape table on stderr")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     a = ap.parse_args()
 
     import torch
     cfg = sd3.SD3Config(layers=a.layers, cn_layers=a.cn_layers, pos_embed_max_size=max(96, a.latent // 2))
-    eng = sd3.SD3Engine(cfg, precision=a.precision, stream_f32=a.stream_f32)
+    eng = sd3.SD3Engine(cfg, precision=a.precision, stream_f32=a.stream_f32, fp8=a.fp8)
     eng.init_random_weights(7)
     for kv in a.opt:
         k, v = kv.split("=")
@@ -82,7 +83,7 @@ def main():
     launches = (eng.base.stat("launches") - n0) / a.repeat / a.steps
     Bf = 2 * B if a.guidance > 1 else B
     fl = step_flops(cfg, Bf, (H // 2) ** 2, S)
-    rec = dict(metric="SD3-medium MMDiT + Prompt-Diffusion ControlNet, seconds per image", precision=a.precision, batch=B,
+    rec = dict(metric="SD3-medium MMDiT + Prompt-Diffusion ControlNet, seconds per image", precision=a.precision + ("+fp8" if a.fp8 else ""), batch=B,
                latent=[H, H], context_tokens=S, steps=a.steps, cn_layers=a.cn_layers, layers=a.layers, guidance=a.guidance,
                s_per_image=dt / B, images_per_s=B / dt, ms_per_step=1e3 * dt / a.steps, tflops_per_step=fl / 1e12,
                path_tflops_per_s=fl * a.steps / dt / 1e12, launches_per_step=launches,
