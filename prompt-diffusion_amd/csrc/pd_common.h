@@ -198,6 +198,10 @@ struct GemmParams {
     // PREC_FP8: acc * a_scale[m] * w_scale[n] before everything else in the epilogue
     const float* a_scale;
     const float* w_scale;
+    // tile order (igemm_kernel): 0 = an XCD's run of tiles is n-fastest over whole rows of tiles; G > 0 = the run is cut into
+    // super-tiles of 4 x G tiles (m x n), so the ~32 blocks an XCD has in flight share 4 A panels and G weight panels instead
+    // of ~1 A panel and every weight panel of a wide layer (fabric -> L2 traffic per K step ~2-3x lower for N >= 16 tiles)
+    int tile_gn;
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)
