@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
 
     // folded LayerNorm: {mean, rstd} of this block's BM rows, combined once from the producer's partials into LDS behind the
     // staging buffers (the epilogue reads two floats per row instead of walking the partials in every lane)
-    constexpr bool LNF = !GG;   // not in the GEGLU instantiations (160 accumulator registers at the VGPR cap): norm3 stays a kernel
+    constexpr bool LNF = !GG && !MM;   // not in the GEGLU instantiations (nor the MMDiT ones: no LayerNorm fold on that path) (160 accumulator registers at the VGPR cap): norm3 stays a kernel
     float2* sLn = reinterpret_cast<float2*>(smem + 2 * (BM + BN) * BKB);
     if constexpr (LNF) {
         if (p.ln_stats && tid < BM) {
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
 
     // Staging registers are NAMED scalars reached through constexpr selectors: hipcc leaves small indexed
     // arrays captured by these lambdas in scratch memory, which serialises every prefetch behind a wait.
-    static_assert(A_ITERS <= 4 && B_ITERS <= 5, "staging registers below cover 4 A and 5 B pieces");
-    uint4 ra0, ra1, ra2, ra3, rh0, rh1, rh2, rh3, rb0, rb1, rb2, rb3, rb4;   // set 0
-    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3, sb4;                       // set 1 (DEPTH 2 only)
+    static_assert(A_ITERS <= 4 && B_ITERS <= 6, "staging registers below cover 4 A and 6 B pieces");
+    uint4 ra0, ra1, ra2, ra3, rh0, rh1, rh2, rh3, rb0, rb1, rb2, rb3, rb4, rb5;   // set 0
+    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3, sb4, sb5;                  // set 1 (DEPTH 2 only)
     auto RA = [&](auto S, auto I) __attribute__((always_inline)) -> uint4& {
         constexpr int i = decltype(I)::value;
         if constexpr (decltype(S)::value == 0) {
@@ -160,10 +160,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
         constexpr int i = decltype(I)::value;
         if constexpr (decltype(S)::value == 0) {
             if constexpr (i == 0) return rb0; else if constexpr (i == 1) return rb1; else if constexpr (i == 2) return rb2;
-            else if constexpr (i == 3) return rb3; else return rb4;
+            else if constexpr (i == 3) return rb3; else if constexpr (i == 4) return rb4; else return rb5;
         } else {
             if constexpr (i == 0) return sb0; else if constexpr (i == 1) return sb1; else if constexpr (i == 2) return sb2;
-            else if constexpr (i == 3) return sb3; else return sb4;
+            else if constexpr (i == 3) return sb3; else if constexpr (i == 4) return sb4; else return sb5;
         }
     };
     unsigned rokmask1 = 0;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmParams p) {
 template <int P, int BM, int BN, int WM, int WN, bool CONV, bool AF32, bool GG = false, bool MM = false>
 int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr int NTHREADS = WM * WN * 64;
-    constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB + BM * 8;   // staging buffers + {mean, rstd} of the block's rows
+    constexpr int SMEM_BYTES = 2 * (BM + BN) * BKB + ((GG || MM) ? 0 : BM * 8);   // staging buffers + {mean, rstd} of the block's rows (LayerNorm fold)
     static unsigned long long attr_done = 0;
     auto kfn = igemm_kernel<P, BM, BN, WM, WN, CONV, AF32, GG, MM>;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM_BYTES, &attr_done)) return 1;
@@ -547,7 +547,10 @@ int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
             return launch_one<P, 256, 192, 4, 2, false, false, false, false>(p, s, mid);
         }
     }
-    if (p.act == 4 || p.gate || p.c_sample_rows || p.a_sample_rows) {   // MMDiT epilogue extras: linear layers over operands of the compute type
+    // (measured and dropped: 128 x 192 four-wave blocks, two per CU so that one block's epilogue runs under the other's K loop
+    // -- 43 % more operand bytes per FLOP through L2 cost more than the overlap gains: SD3 step 36.1 -> 37.4 ms)
+    if (p.act == 4 || p.gate || p.c_sample_rows || p.a_sample_rows) {   // MMDiT epilogue extras
+        if (p.ln_stats || p.stats_out) return 1;   // no LayerNorm fold in the MM instantiations: linear layers over operands of the compute type
         if (conv || af32) return 1;
         if constexpr (F) {
             if (tile == 1 || tile == 3) return launch_one<P, 256, 160, 4, 2, false, false, false, true>(p, s, mid);
