@@ -111,6 +111,43 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def sd3_leg(precision, device):
+    """Context only (not the metric): the SD3 / MMDiT variant of the path (BASELINE config #5) at
+    SD3-medium size + a 6-block ControlNet, 1024x1024 (4096 image + 333 context tokens), CFG, random-init weights: 10 Euler
+    steps timed after a warm-up pass, without and with e4m3 operands on the AdaLN-fed projections ("fp8 MFMA")."""
+    import torch
+    from prompt_diffusion_amd import sd3
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sd3_bench import step_flops
+    out = {"workload": "SD3-medium MMDiT + 6-block Prompt-Diffusion ControlNet, 1024x1024, CFG 7 (forward batch 2), per Euler step",
+           "parity": "unpinned (diffusers absent offline; oracle/sd3_oracle.py)"}
+    cfg = sd3.SD3Config(pos_embed_max_size=96)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    f = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x, cond, pair = f(1, 16, 128, 128), f(1, 16, 128, 128), f(1, 16, 128, 128)
+    ctx, nctx, pool, npool = f(1, 333, cfg.joint_dim), f(1, 333, cfg.joint_dim), f(1, cfg.pooled_dim), f(1, cfg.pooled_dim)
+    fl = step_flops(cfg, 2, 4096, 333)
+    steps = 10
+    try:
+        for name, fp8 in (("f16" if precision == "f16" else precision, False), (precision + "+fp8", True)):
+            e = sd3.SD3Engine(cfg, device=device, precision=precision, fp8=fp8)
+            e.init_random_weights(7)
+            run = lambda: e.sample(x, ctx, pool, nctx, npool, control_latents=cond, pair_latents=pair, num_inference_steps=steps,
+                                   guidance_scale=7.0)
+            o = run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = run()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert torch.isfinite(o).all()
+            out[name] = {"ms_per_step": 1e3 * dt / steps, "s_per_28_step_image": 28 * dt / steps, "path_tflops_per_s": fl * steps / dt / 1e12}
+            e.close()
+    except Exception as ex:   # noqa: BLE001 - context only
+        out["error"] = str(ex)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +164,7 @@ def main():
     ap.add_argument("--no-f32", "--no-extra-modes", dest="no_f32", action="store_true",
                     help="skip the extra measurement of the f16x2 mode (fp32-class results) on the same workload")
     ap.add_argument("--no-parity", action="store_true", help="skip the per-step latent error leg")
+    ap.add_argument("--no-sd3", action="store_true", help="skip the SD3 / MMDiT leg (SURVEY N4 / BASELINE config #5, context only)")
     ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=int (experiments)")
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise ControlNet and UNet on one stream in every pass (used for the committed rocprof summary, so\n"
@@ -318,6 +356,8 @@ def main():
             result["f16x2_mode"] = {"value": B / d2, "unit": "images/sec", "ms_per_step": 1e3 * d2, "dtype": "f16x2",
                                     "path_tflops": B / d2 * tflop_image}
             e2.close()
+        if not args.no_sd3 and world == 1 and args.precision in ("f16", "bf16"):
+            result["sd3_leg"] = sd3_leg(args.precision, local)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(result))

@@ -3,7 +3,7 @@
 for spec in "$@"; do
   name=${spec%%:*}; opts=${spec#*:}; args=""
   if [ "$opts" != "$spec" ] && [ -n "$opts" ]; then for o in ${opts//,/ }; do args="$args --opt $o"; done; fi
-  timeout -k 10 300 python bench.py --no-cpu-baseline --no-f32 --no-profile --steps 2 $args > gpurun_out/ab_$name.log 2>&1 || { echo "$name FAILED"; tail -3 gpurun_out/ab_$name.log; exit 1; }
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-f32 --no-profile --no-sd3 --steps 2 $args > gpurun_out/ab_$name.log 2>&1 || { echo "$name FAILED"; tail -3 gpurun_out/ab_$name.log; exit 1; }
   python - "$name" <<'PY'
 import json,sys
 d=json.loads(open(f"gpurun_out/ab_{sys.argv[1]}.log").read().strip().split("\n")[-1])
