@@ -335,7 +335,7 @@ struct pd_engine {
     };
     void build_sd3_net(const std::string& prefix, Sd3NetW& net, bool controlnet);
     int sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs, Act& c, Act& modbuf);
-    int sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt);
+    int sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt, const Act* pre_add = nullptr);
     int sd3_forward(const Sd3Io& io, float* v_out_dev, int control_index, float* control_out_dev);
     // one-shot extras of the next gemm() call (MMDiT: gated residual, joint-buffer row remap)
     struct GemmExtra { const float* a_scale = nullptr; const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0, a_sample_rows = 0, a_row_off = 0; } gx;

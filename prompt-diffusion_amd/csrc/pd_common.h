@@ -264,9 +264,9 @@ int launch_cfg_ddim(const void* eps, int eps_dt, int eps_C, float* x_state, floa
                     float temperature, int do_update, hipStream_t s);
 int launch_fill_random(void* p, int dt, long long n, float scale, float shift, uint64_t seed, hipStream_t s);
 // sd3_kernels.hip: element-wise pieces of the MMDiT path
-// y_dt == DT_FP8: y holds e4m3 bytes and y_scale[row] the row's scale (max |value| / 448)
+// y_dt == DT_FP8: y holds e4m3 bytes and y_scale[row] the row's scale (max |value| / 448); add: x <- x + add first (written back)
 int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, int mod_stride, int shift_off, int scale_off, int rows,
-                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale = nullptr);
+                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale = nullptr, const void* add = nullptr);
 int launch_patchify(const float* nchw, void* out, int out_dt, int B, int C, int H, int W, int patch, int Cpad, int Kpad, hipStream_t s);
 int launch_pos_crop(const float* table, float* out, int B, int h, int w, int max_size, int D, hipStream_t s);
 int launch_unpatchify(const void* in, int in_dt, int ld, float* nchw, int B, int C, int h, int w, int patch, hipStream_t s);

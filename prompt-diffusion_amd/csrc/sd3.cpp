@@ -178,7 +178,8 @@ int pd_engine::sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs
 // JointTransformerBlock.forward (diffusers attention.py; MMDiT block of Esser et al. Fig. 2b); x, c updated in place.
 // qk: joint q|k buffer [B, N + S, 2D]; vt: joint V^T [B, D, pad(N + S)] with zeroed pad columns (both owned by the caller:
 // the same pair serves every block of a network, so the pad is cleared once per evaluation).
-int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt) {
+// pre_add: x += *pre_add before anything else (folded into the first AdaLN pass).
+int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt, const Act* pre_add) {
     const int D = x.C, B = x.B, N = x.H, Sx = c.H, Nt = N + Sx, heads = sd3.heads;
     const size_t eb = dt_size(T);
     const float* mod = reinterpret_cast<const float*>(modbuf.p);
@@ -188,11 +189,11 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     // with one scale per token, and those GEMMs run in PREC_FP8 against the layers' quantised weights
     const bool f8 = opt_sd3_fp8 && !f32;
     const int NT = f8 ? DT_FP8 : T;
-    auto adaln = [&](const Act& in, Act& out, int shift_off, int scale_off, float* row_scale) -> int {
+    auto adaln = [&](const Act& in, Act& out, int shift_off, int scale_off, float* row_scale, const void* add = nullptr) -> int {
         if (arena.dry) return 0;
         PD_TRY(check_arena());
         ++launches;
-        if (launch_adaln(in.p, in.dt, out.p, out.dt, mod, ms, shift_off, scale_off, (int)in.rows(), in.H, D, 1e-6f, stream, row_scale)) {
+        if (launch_adaln(in.p, in.dt, out.p, out.dt, mod, ms, shift_off, scale_off, (int)in.rows(), in.H, D, 1e-6f, stream, row_scale, add)) {
             pd_set_error("sd3: AdaLN launch failed (C=%d)", D);
             return 1;
         }
@@ -201,7 +202,8 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     auto scales = [&](int rows) { return f8 ? reinterpret_cast<float*>(arena.alloc((size_t)rows * sizeof(float))) : nullptr; };
     Act xn = new_act(B, N, 1, D, NT), cn = new_act(B, Sx, 1, D, NT);
     float *xs = scales(B * N), *cs = scales(B * Sx);
-    PD_TRY(adaln(x, xn, b.mod_off, b.mod_off + D, xs));                         // (shift_msa, scale_msa, gate_msa, shift_mlp, ...)
+    if (pre_add && pre_add->dt != x.dt) { pd_set_error("internal: residual dtype mismatch"); return 1; }
+    PD_TRY(adaln(x, xn, b.mod_off, b.mod_off + D, xs, pre_add ? pre_add->p : nullptr));   // (shift_msa, scale_msa, gate_msa, shift_mlp, ...)
     if (b.pre_only) PD_TRY(adaln(c, cn, b.mod_c_off + D, b.mod_c_off, cs));     // AdaLayerNormContinuous: (scale, shift)
     else PD_TRY(adaln(c, cn, b.mod_c_off, b.mod_c_off + D, cs));
     // both QKV GEMMs store straight into the joint buffers
@@ -331,17 +333,12 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
         if (!arena.dry && vt_ld != Nt) HIP_OK(hipMemsetAsync(vt.p, 0, vt.bytes(), stream));   // pad keys of V^T must read as 0
     }
     const int interval = control.empty() ? 0 : (net.layers + (int)control.size() - 1) / (int)control.size();
+    // hidden_states + block_controlnet_hidden_states[i // interval] after block i (every block but the last): the add rides
+    // on the next block's first AdaLN pass
+    const Act* pending = nullptr;
     for (int i = 0; i < net.layers; ++i) {
-        PD_TRY(sd3_block(net.blocks[i], hs, c, modbuf, qk, vt));
-        if (interval && !net.blocks[i].pre_only) {   // hidden_states + block_controlnet_hidden_states[i // interval]
-            if (!arena.dry) {
-                ++launches;
-                if (launch_add_inplace(hs.p, control[i / interval].p, hs.dt, (long long)hs.rows() * D, stream)) {
-                    pd_set_error("sd3: residual add launch failed");
-                    return 1;
-                }
-            }
-        }
+        PD_TRY(sd3_block(net.blocks[i], hs, c, modbuf, qk, vt, pending));
+        pending = (interval && !net.blocks[i].pre_only) ? &control[i / interval] : nullptr;
     }
     // norm_out (AdaLayerNormContinuous: scale, shift) + proj_out + unpatchify
     Act nx = new_act(B, N, 1, D, T);

@@ -8,10 +8,13 @@ __device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.
 // AdaLayerNormZero / AdaLayerNormContinuous body: y = LN(x) (no affine, eps) * (1 + scale[b]) + shift[b].
 // One wave per row, the row held in registers between the two passes; C <= 2048, C % 4 == 0.
 // mod: fp32 [B][mod_stride] (output of the modulation GEMM), the chunk of this norm at shift_off / scale_off.
+// add (optional, dtype of x): x <- x + add first, written back -- the ControlNet residual that lands on the residual stream
+// between two blocks, taken in by the next block's first norm instead of a pass of its own.
 template <int XD, int YD>
 __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ mod,
                                                      int mod_stride, int shift_off, int scale_off, int rows, int rows_per_sample,
-                                                     int C, float eps, float* __restrict__ y_scale) {
+                                                     int C, float eps, float* __restrict__ y_scale, void* __restrict__ x_rw,
+                                                     const void* __restrict__ add) {
     constexpr int MAXV = 8;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -23,6 +26,19 @@ __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, 
     for (int k = 0; k < MAXV; ++k) {
         const int vi = lane + 64 * k;
         v[k] = vi < nv ? load4(x, (size_t)row * C + (size_t)vi * 4, XD) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (add && vi < nv) {
+            v[k] += load4(add, (size_t)row * C + (size_t)vi * 4, XD);
+            store4(x_rw, (size_t)row * C + (size_t)vi * 4, XD, v[k]);
+            if constexpr (XD != DT_F32) {   // normalise what the stream now holds (the rounded sum), like a separate add pass would
+                uint2 u;
+                u.x = pack2<XD>(v[k][0], v[k][1]);
+                u.y = pack2<XD>(v[k][2], v[k][3]);
+                float a0, a1, a2, a3;
+                unpack2<XD>(u.x, a0, a1);
+                unpack2<XD>(u.y, a2, a3);
+                v[k] = f32x4{a0, a1, a2, a3};
+            }
+        }
         s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
     }
 #pragma unroll
@@ -77,13 +93,14 @@ __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, 
 }
 
 int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, int mod_stride, int shift_off, int scale_off, int rows,
-                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale) {
+                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale, const void* add) {
+    void* x_rw = const_cast<void*>(x);   // written only when add is given
     if (C % 4 || C > 2048 || rows < 1 || rows_per_sample < 1 || (mod_stride | shift_off | scale_off) % 4) return 1;
     if (y_dt == DT_FP8 && !y_scale) return 1;
     const dim3 grid((rows + 3) / 4);
 #define PD_ADALN(XD, YD)                                                                                                       \
     hipLaunchKernelGGL((adaln_kernel<XD, YD>), grid, dim3(256), 0, s, x, y, mod, mod_stride, shift_off, scale_off, rows, \
-                       rows_per_sample, C, eps, y_scale)
+                       rows_per_sample, C, eps, y_scale, x_rw, add)
     if (x_dt == DT_F32 && y_dt == DT_F32) PD_ADALN(DT_F32, DT_F32);
     else if (x_dt == DT_F32 && y_dt == DT_F16) PD_ADALN(DT_F32, DT_F16);
     else if (x_dt == DT_F32 && y_dt == DT_BF16) PD_ADALN(DT_F32, DT_BF16);
