@@ -48,6 +48,22 @@ def linear_fp8(x, w, b=None):
     return (y if b is None else y + b).astype(F32)
 
 
+def ff_fp8_bounded(xn, w1, b1, w2, b2):
+    """The engine's sd3_fp8 level 2 feed-forward: net.0 as linear_fp8, its GELU output stored as e4m3 under the row scale
+    (1.13 |xn_row|_2 max_n |W1_n|_2 + max |b1|) / 448 (a Cauchy-Schwarz bound, known before the GEMM runs), net.2 on e4m3
+    operands with that scale and per-output-channel weight scales."""
+    h = gelu_tanh(linear_fp8(xn, w1, b1))
+    wn = F32(np.sqrt((w1.astype(np.float64) ** 2).sum(-1)).max())
+    bm = F32(np.abs(b1).max())
+    rn = np.sqrt((xn.astype(np.float64) ** 2).sum(-1, keepdims=True)).astype(F32)
+    sc = (rn * (F32(1.13) * wn / F32(448.0)) + bm / F32(448.0)).astype(F32)
+    hq = quant_e4m3(h * (F32(1.0) / sc))
+    amax = np.abs(w2).max(-1, keepdims=True)
+    ws = np.where(amax > 0, amax * F32(1.0 / 448.0), F32(1.0)).astype(F32)
+    wq = quant_e4m3(w2 * (F32(1.0) / ws))
+    return ((hq @ wq.T) * sc * ws[:, 0] + b2).astype(F32)
+
+
 def silu(x):
     return x / (1.0 + np.exp(-x))
 
@@ -110,9 +126,10 @@ def attention(q, k, v, heads):
 
 def joint_block(sd, pre, cfg, x, c, temb, context_pre_only, fp8=False):
     """JointTransformerBlock: AdaLN-Zero on both streams, attention over [image ; context] tokens, gated residuals.
-    fp8: the engine's sd3_fp8 option -- the projections fed by an AdaLN output (q/k/v of both streams, ff / ff_context net.0)
-    take e4m3 operands (linear_fp8)."""
+    fp8: the engine's sd3_fp8 option (0 / False, 1, 2) -- the projections fed by an AdaLN output (q/k/v of both streams,
+    ff / ff_context net.0) take e4m3 operands (linear_fp8); level 2 also the feed-forward-out projections (ff_fp8_bounded)."""
     P = lambda n: sd[pre + n]
+    fp8 = int(fp8)
     qlinear = linear_fp8 if fp8 else linear
     e = silu(temb)
     m = linear(e, P("norm1.linear.weight"), P("norm1.linear.bias"))
@@ -136,15 +153,22 @@ def joint_block(sd, pre, cfg, x, c, temb, context_pre_only, fp8=False):
     ox = linear(o[:, :N], P("attn.to_out.0.weight"), P("attn.to_out.0.bias"))
     x = x + g_a[:, None] * ox
     xn2 = layer_norm_noaffine(x) * (1 + sc_m[:, None]) + sh_m[:, None]
-    ff = linear(gelu_tanh(qlinear(xn2, P("ff.net.0.proj.weight"), P("ff.net.0.proj.bias"))), P("ff.net.2.weight"), P("ff.net.2.bias"))
+    if fp8 >= 2:
+        ff = ff_fp8_bounded(xn2, P("ff.net.0.proj.weight"), P("ff.net.0.proj.bias"), P("ff.net.2.weight"), P("ff.net.2.bias"))
+    else:
+        ff = linear(gelu_tanh(qlinear(xn2, P("ff.net.0.proj.weight"), P("ff.net.0.proj.bias"))), P("ff.net.2.weight"), P("ff.net.2.bias"))
     x = (x + g_m[:, None] * ff).astype(F32)
     if context_pre_only:
         return None, x
     oc = linear(o[:, N:], P("attn.to_add_out.weight"), P("attn.to_add_out.bias"))
     c = c + c_g_a[:, None] * oc
     cn2 = layer_norm_noaffine(c) * (1 + c_sc_m[:, None]) + c_sh_m[:, None]
-    ffc = linear(gelu_tanh(qlinear(cn2, P("ff_context.net.0.proj.weight"), P("ff_context.net.0.proj.bias"))),
-                 P("ff_context.net.2.weight"), P("ff_context.net.2.bias"))
+    if fp8 >= 2:
+        ffc = ff_fp8_bounded(cn2, P("ff_context.net.0.proj.weight"), P("ff_context.net.0.proj.bias"),
+                             P("ff_context.net.2.weight"), P("ff_context.net.2.bias"))
+    else:
+        ffc = linear(gelu_tanh(qlinear(cn2, P("ff_context.net.0.proj.weight"), P("ff_context.net.0.proj.bias"))),
+                     P("ff_context.net.2.weight"), P("ff_context.net.2.bias"))
     c = (c + c_g_m[:, None] * ffc).astype(F32)
     return c, x
 

@@ -619,12 +619,14 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     p.gate = gx.gate; p.gate_stride = gx.gate_stride;
     p.c_sample_rows = gx.c_sample_rows; p.c_row_off = gx.c_row_off; p.vt_tok_off = gx.vt_tok_off;
     p.a_sample_rows = gx.a_sample_rows; p.a_row_off = gx.a_row_off;
+    p.c_scale = gx.c_scale;
+    if (out.dt == DT_FP8 && !gx.c_scale) { pd_set_error("internal: fp8 output without row scales"); return 1; }
     const bool fp8 = in.dt == DT_FP8;
     if (fp8) {   // e4m3 operands with per-row scales: the layer's quantised copy
         if (!m.w8 || !gx.a_scale || m.taps != 1 || m.geglu) { pd_set_error("internal: fp8 GEMM without quantised weights / row scales"); return 1; }
         p.W = m.w8; p.Kpad = m.Kpad8; p.w_scale = m.wscale; p.a_scale = gx.a_scale;
     }
-    const bool plain = !gx.gate && !gx.c_sample_rows && !gx.a_sample_rows;
+    const bool plain = !gx.gate && !gx.c_sample_rows && !gx.a_sample_rows && !gx.c_scale;
     gx = GemmExtra{};
     // a handful of fp32 rows against a wide weight matrix: stream the weights once (gemm.hip's tiles would spend a 128-row
     // tile on <= 4 rows and run at a third of the HBM rate)
@@ -679,7 +681,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         int splitk = 1;
         // linear layers with a short K and at least half a chip of tiles: one 8-wave block per CU instead of split-K
         const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !fp8 && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
-        if (!fp8 && !dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
+        if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
             splitk = (512 + tiles - 1) / tiles;
             if (splitk > ktiles / 8) splitk = ktiles / 8;
             if (splitk > opt_splitk_max) splitk = opt_splitk_max;

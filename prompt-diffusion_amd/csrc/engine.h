@@ -45,6 +45,7 @@ struct WMat {
     void* w8 = nullptr;
     float* wscale = nullptr;
     int Kpad8 = 0;
+    float wnorm_max = 0.f, bias_max = 0.f;   // max_n |W_n|_2 and max |bias|: bound of this layer's outputs from its input row's norm
 };
 
 // LayerNorm statistics handed from the GEMM that writes a residual-stream tensor to the GEMM that consumes its LayerNorm
@@ -338,8 +339,8 @@ struct pd_engine {
     int sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt, const Act* pre_add = nullptr);
     int sd3_forward(const Sd3Io& io, float* v_out_dev, int control_index, float* control_out_dev);
     // one-shot extras of the next gemm() call (MMDiT: gated residual, joint-buffer row remap)
-    struct GemmExtra { const float* a_scale = nullptr; const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0, a_sample_rows = 0, a_row_off = 0; } gx;
-    bool opt_sd3_fp8 = false;  // SD3 path: QKV and feed-forward-in projections in PREC_FP8 (e4m3 operands, per-row scales)
+    struct GemmExtra { const float* a_scale = nullptr; const float* c_scale = nullptr; const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0, a_sample_rows = 0, a_row_off = 0; } gx;
+    int opt_sd3_fp8 = 0;       // 0 off, 1: the AdaLN-fed projections, 2: also the feed-forward-out projections (e4m3 GELU output under a norm bound)  // SD3 path: QKV and feed-forward-in projections in PREC_FP8 (e4m3 operands, per-row scales)
     bool sd3_fp8_dirty = true;
     int sd3_quantize();        // (re)builds the e4m3 weights of those layers after a weight change
     bool opt_gemv = true;     // Linear over <= 4 fp32 rows with a wide output (MMDiT modulation): weight-streaming kernel instead of a GEMM tile

@@ -517,7 +517,8 @@ int gemm_tiles(int M, int N) { return ((M + 127) / 128) * ((N + 159) / 160); }
 namespace {
 // PREC_FP8: linear layers with the MMDiT epilogue only (the SD3 path's QKV and feed-forward-in projections)
 int launch_fp8(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
-    if (p.taps != 1 || p.a_dt != DT_FP8 || !p.a_scale || !p.w_scale || p.act == 2 || p.splitk > 1 || p.Kpad % 128) return 1;
+    if (p.taps != 1 || p.a_dt != DT_FP8 || !p.a_scale || !p.w_scale || p.act == 2 || p.Kpad % 128) return 1;
+    if (p.splitk > 1) return launch_one<PREC_FP8, 128, 160, 2, 2, false, false, false, true>(p, s, mid);   // fp32 slabs; the finalize pass applies the scales
     if (p.big_tile == 4) return launch_one<PREC_FP8, 256, 192, 4, 2, false, false, false, true>(p, s, mid);
     if (p.big_tile == 1 || p.big_tile == 3) return launch_one<PREC_FP8, 256, 160, 4, 2, false, false, false, true>(p, s, mid);
     return launch_one<PREC_FP8, 128, 160, 2, 2, false, false, false, true>(p, s, mid);

@@ -198,6 +198,9 @@ struct GemmParams {
     // PREC_FP8: acc * a_scale[m] * w_scale[n] before everything else in the epilogue
     const float* a_scale;
     const float* w_scale;
+    // c_dt == DT_FP8 (MM instantiations): the output rows are written as e4m3 of value / c_scale[row]; the caller guarantees
+    // |value| <= 448 c_scale[row] (sd3.cpp: a Cauchy-Schwarz bound from the input row's norm)
+    const float* c_scale;
     // tile order (igemm_kernel): 0 = an XCD's run of tiles is n-fastest over whole rows of tiles; G > 0 = the run is cut into
     // super-tiles of 4 x G tiles (m x n), so the ~32 blocks an XCD has in flight share 4 A panels and G weight panels instead
     // of ~1 A panel and every weight panel of a wide layer (fabric -> L2 traffic per K step ~2-3x lower for N >= 16 tiles)
@@ -266,7 +269,10 @@ int launch_fill_random(void* p, int dt, long long n, float scale, float shift, u
 // sd3_kernels.hip: element-wise pieces of the MMDiT path
 // y_dt == DT_FP8: y holds e4m3 bytes and y_scale[row] the row's scale (max |value| / 448); add: x <- x + add first (written back)
 int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, int mod_stride, int shift_off, int scale_off, int rows,
-                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale = nullptr, const void* add = nullptr);
+                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale = nullptr, const void* add = nullptr,
+                 float* bound_out = nullptr, float bound_mul = 0.f, float bound_add = 0.f);   // bound_out[row] = |y_row|_2 * mul + add
+// max over rows of the row L2 norm of W (dtype dt, row stride ld) and max |bias| -> out[0], out[1] (fp32, device, zeroed by the caller)
+int launch_rows_norm_max(const void* W, int dt, int ld, const float* bias, int rows, int K, float* out, hipStream_t s);
 int launch_patchify(const float* nchw, void* out, int out_dt, int B, int C, int H, int W, int patch, int Cpad, int Kpad, hipStream_t s);
 int launch_pos_crop(const float* table, float* out, int B, int h, int w, int max_size, int D, hipStream_t s);
 int launch_unpatchify(const void* in, int in_dt, int ld, float* nchw, int B, int C, int h, int w, int patch, hipStream_t s);

@@ -204,6 +204,13 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, 
         size_t crow = (size_t)gm;
         if constexpr (MM) {
             if (p.c_sample_rows) crow = (size_t)sample * p.c_sample_rows + p.c_row_off + tok;
+            if (p.c_dt == DT_FP8) {   // e4m3 of value / c_scale[row] (the bound makes the clamp a no-op up to rounding)
+                const float inv = __builtin_amdgcn_rcpf(p.c_scale[crow]);
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0] * inv, -448.f), 448.f), fminf(fmaxf(v[1] * inv, -448.f), 448.f), 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2] * inv, -448.f), 448.f), fminf(fmaxf(v[3] * inv, -448.f), 448.f), w, true);
+                *reinterpret_cast<int*>(reinterpret_cast<char*>(p.C) + crow * p.ldc + gn) = w;
+                return v;
+            }
         }
         store4(p.C, crow * p.ldc + gn, p.c_dt, v);
     }

@@ -187,13 +187,21 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     const size_t mk = arena.mark();
     // option sd3_fp8 (2-byte modes): the AdaLN outputs feeding the QKV and feed-forward-in projections are written as e4m3
     // with one scale per token, and those GEMMs run in PREC_FP8 against the layers' quantised weights
-    const bool f8 = opt_sd3_fp8 && !f32;
+    const bool f8 = opt_sd3_fp8 && !f32, f8b = opt_sd3_fp8 >= 2 && !f32;
     const int NT = f8 ? DT_FP8 : T;
-    auto adaln = [&](const Act& in, Act& out, int shift_off, int scale_off, float* row_scale, const void* add = nullptr) -> int {
+    // level 2: the feed-forward-out projection reads an e4m3 GELU output too.  No kernel sees a whole row of it before it
+    // is written, so its row scale is a bound known beforehand: |GELU(W y + b)|_inf <= |y|_2 max_n |W_n|_2 + max |b|
+    // (Cauchy-Schwarz; ~10x above the actual row maximum, which costs e4m3 nothing but subnormal range), emitted by the AdaLN
+    // pass that produces y.  1.13 covers the e4m3 rounding of y and W (each <= 2^-4 relative).
+    constexpr float kBoundMargin = 1.13f;
+    auto adaln = [&](const Act& in, Act& out, int shift_off, int scale_off, float* row_scale, const void* add = nullptr,
+                     float* bound_out = nullptr, const WMat* consumer = nullptr) -> int {
         if (arena.dry) return 0;
         PD_TRY(check_arena());
         ++launches;
-        if (launch_adaln(in.p, in.dt, out.p, out.dt, mod, ms, shift_off, scale_off, (int)in.rows(), in.H, D, 1e-6f, stream, row_scale, add)) {
+        const float bmul = consumer ? kBoundMargin * consumer->wnorm_max / 448.0f : 0.f, badd = consumer ? consumer->bias_max / 448.0f : 0.f;
+        if (launch_adaln(in.p, in.dt, out.p, out.dt, mod, ms, shift_off, scale_off, (int)in.rows(), in.H, D, 1e-6f, stream, row_scale, add,
+                         bound_out, bmul, badd)) {
             pd_set_error("sd3: AdaLN launch failed (C=%d)", D);
             return 1;
         }
@@ -233,22 +241,24 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     {
         Act n2 = new_act(B, N, 1, D, NT);
         float* ns = scales(B * N);
-        PD_TRY(adaln(x, n2, b.mod_off + 3 * D, b.mod_off + 4 * D, ns));
-        Act f = new_act(B, N, 1, 4 * D, T);
-        gx.a_scale = ns;
+        float* fs = f8b ? scales(B * N) : nullptr;
+        PD_TRY(adaln(x, n2, b.mod_off + 3 * D, b.mod_off + 4 * D, ns, nullptr, fs, f8b ? &b.ff1 : nullptr));
+        Act f = new_act(B, N, 1, 4 * D, f8b ? DT_FP8 : T);
+        gx.a_scale = ns; gx.c_scale = fs;
         PD_TRY(gemm(b.ff1, n2, f, 1, 0, /*tanh-GELU*/ 4, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
-        gx.gate = mod + b.mod_off + 5 * D; gx.gate_stride = ms;
+        gx.gate = mod + b.mod_off + 5 * D; gx.gate_stride = ms; gx.a_scale = fs;
         PD_TRY(gemm(b.ff2, f, x, 1, 0, 0, 1.f, &x, nullptr, 0, false, nullptr, 0, 0));
         arena.release(mk);
     }
     if (!b.pre_only) {
         Act n2 = new_act(B, Sx, 1, D, NT);
         float* ns = scales(B * Sx);
-        PD_TRY(adaln(c, n2, b.mod_c_off + 3 * D, b.mod_c_off + 4 * D, ns));
-        Act f = new_act(B, Sx, 1, 4 * D, T);
-        gx.a_scale = ns;
+        float* fs = f8b ? scales(B * Sx) : nullptr;
+        PD_TRY(adaln(c, n2, b.mod_c_off + 3 * D, b.mod_c_off + 4 * D, ns, nullptr, fs, f8b ? &b.ffc1 : nullptr));
+        Act f = new_act(B, Sx, 1, 4 * D, f8b ? DT_FP8 : T);
+        gx.a_scale = ns; gx.c_scale = fs;
         PD_TRY(gemm(b.ffc1, n2, f, 1, 0, 4, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
-        gx.gate = mod + b.mod_c_off + 5 * D; gx.gate_stride = ms;
+        gx.gate = mod + b.mod_c_off + 5 * D; gx.gate_stride = ms; gx.a_scale = fs;
         PD_TRY(gemm(b.ffc2, f, c, 1, 0, 0, 1.f, &c, nullptr, 0, false, nullptr, 0, 0));
         arena.release(mk);
     }
@@ -258,27 +268,48 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
 // e4m3 copies (one scale per output row) of the layers option sd3_fp8 runs in PREC_FP8
 int pd_engine::sd3_quantize() {
     if (!opt_sd3_fp8 || f32 || !sd3_fp8_dirty) return 0;
+    float* red = nullptr;   // {max row norm, max |bias|} of one layer
+    HIP_OK(hipMalloc(&red, 2 * sizeof(float)));
+    int r = 0;
     for (Sd3NetW* net : {&sd3_tr, &sd3_cn}) {
         if (!net->built) continue;
         for (Sd3BlockW& b : net->blocks) {
-            WMat* mats[4] = {&b.qkv, &b.qkv_c, &b.ff1, b.pre_only ? nullptr : &b.ffc1};
-            for (WMat* m : mats) {
+            const bool l2 = opt_sd3_fp8 >= 2;
+            WMat* mats[6] = {&b.qkv, &b.qkv_c, &b.ff1, b.pre_only ? nullptr : &b.ffc1, l2 ? &b.ff2 : nullptr,
+                             (l2 && !b.pre_only) ? &b.ffc2 : nullptr};
+            for (int i = 0; i < 6 && !r; ++i) {
+                WMat* m = mats[i];
                 if (!m) continue;
                 if (!m->w8) {
                     m->Kpad8 = round_up(m->K, 128);
                     m->w8 = dmalloc((size_t)m->N * m->Kpad8);
                     m->wscale = reinterpret_cast<float*>(dmalloc((size_t)(m->N + 4) * sizeof(float)));
-                    if (!m->w8 || !m->wscale) { pd_set_error("allocation of fp8 weights failed"); return 1; }
+                    if (!m->w8 || !m->wscale) { pd_set_error("allocation of fp8 weights failed"); r = 1; break; }
                 }
                 if (launch_quant_rows(m->w, T, m->Kpad, m->w8, m->Kpad8, m->wscale, m->N, m->K, stream)) {
                     pd_set_error("fp8 weight quantisation launch failed");
-                    return 1;
+                    r = 1;
+                    break;
+                }
+                if (l2 && (i == 2 || i == 3)) {   // feed-forward-in layers: the bound of their outputs (see sd3_block)
+                    float host[2] = {0.f, 0.f};
+                    if (hipMemsetAsync(red, 0, sizeof(host), stream) != hipSuccess ||
+                        launch_rows_norm_max(m->w, T, m->Kpad, m->bias, m->Nout, m->K, red, stream) ||
+                        hipMemcpyAsync(host, red, sizeof(host), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                        hipStreamSynchronize(stream) != hipSuccess) {
+                        pd_set_error("weight norm reduction failed");
+                        r = 1;
+                        break;
+                    }
+                    m->wnorm_max = host[0];
+                    m->bias_max = host[1];
                 }
             }
         }
     }
-    sd3_fp8_dirty = false;
-    return 0;
+    hipFree(red);
+    if (!r) sd3_fp8_dirty = false;
+    return r;
 }
 
 // ControlNet (when io.cond) then transformer.  control_index >= 0: stop after the ControlNet and copy that residual out.

@@ -14,7 +14,8 @@ template <int XD, int YD>
 __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ mod,
                                                      int mod_stride, int shift_off, int scale_off, int rows, int rows_per_sample,
                                                      int C, float eps, float* __restrict__ y_scale, void* __restrict__ x_rw,
-                                                     const void* __restrict__ add) {
+                                                     const void* __restrict__ add, float* __restrict__ bound_out, float bound_mul,
+                                                     float bound_add) {
     constexpr int MAXV = 8;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, 
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = 1.0f / sqrtf(q / (float)C + eps);
     const float* mrow = mod + (size_t)(row / rows_per_sample) * mod_stride;
-    float amax = 0.f;
+    float amax = 0.f, sq = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         const int vi = lane + 64 * k;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, 
             if constexpr (YD == DT_FP8) {
                 v[k] = o;
                 amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                sq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
             } else {
                 store4(y, (size_t)row * C + (size_t)vi * 4, YD, o);
             }
@@ -80,6 +82,11 @@ __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, 
         const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
         const float inv = 1.0f / scale;
         if (lane == 0) y_scale[row] = scale;
+        if (bound_out) {   // |W y|_inf <= |y|_2 max_n |W_n|_2: the row scale of the consuming layer's e4m3 OUTPUT
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            if (lane == 0) bound_out[row] = fmaf(sqrtf(sq), bound_mul, bound_add);
+        }
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
             const int vi = lane + 64 * k;
@@ -93,14 +100,15 @@ __global__ __launch_bounds__(256) void adaln_kernel(const void* __restrict__ x, 
 }
 
 int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, int mod_stride, int shift_off, int scale_off, int rows,
-                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale, const void* add) {
+                 int rows_per_sample, int C, float eps, hipStream_t s, float* y_scale, const void* add, float* bound_out,
+                 float bound_mul, float bound_add) {
     void* x_rw = const_cast<void*>(x);   // written only when add is given
     if (C % 4 || C > 2048 || rows < 1 || rows_per_sample < 1 || (mod_stride | shift_off | scale_off) % 4) return 1;
     if (y_dt == DT_FP8 && !y_scale) return 1;
     const dim3 grid((rows + 3) / 4);
 #define PD_ADALN(XD, YD)                                                                                                       \
     hipLaunchKernelGGL((adaln_kernel<XD, YD>), grid, dim3(256), 0, s, x, y, mod, mod_stride, shift_off, scale_off, rows, \
-                       rows_per_sample, C, eps, y_scale, x_rw, add)
+                       rows_per_sample, C, eps, y_scale, x_rw, add, bound_out, bound_mul, bound_add)
     if (x_dt == DT_F32 && y_dt == DT_F32) PD_ADALN(DT_F32, DT_F32);
     else if (x_dt == DT_F32 && y_dt == DT_F16) PD_ADALN(DT_F32, DT_F16);
     else if (x_dt == DT_F32 && y_dt == DT_BF16) PD_ADALN(DT_F32, DT_BF16);
@@ -357,6 +365,36 @@ int launch_quant_rows(const void* src, int src_dt, int src_ld, void* dst, int ds
     if (src_dt == DT_F32) hipLaunchKernelGGL((quant_rows_kernel<DT_F32>), grid, dim3(256), 0, s, src, src_ld, d, dst_ld, scale, rows, K);
     else if (src_dt == DT_F16) hipLaunchKernelGGL((quant_rows_kernel<DT_F16>), grid, dim3(256), 0, s, src, src_ld, d, dst_ld, scale, rows, K);
     else if (src_dt == DT_BF16) hipLaunchKernelGGL((quant_rows_kernel<DT_BF16>), grid, dim3(256), 0, s, src, src_ld, d, dst_ld, scale, rows, K);
+    else return 1;
+    return hipGetLastError() != hipSuccess;
+}
+
+// max_n |W_n|_2 and max |bias| (one wave per row; non-negative floats compare like their bit patterns)
+template <int XD>
+__global__ __launch_bounds__(256) void rows_norm_max_kernel(const void* __restrict__ W, int ld, const float* __restrict__ bias, int rows, int K,
+                                                             float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float sq = 0.f;
+    for (int v = lane; v < K / 4; v += 64) {
+        const f32x4 t = load4(W, (size_t)row * ld + (size_t)v * 4, XD);
+        sq += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) {
+        atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(sqrtf(sq)));
+        if (bias) atomicMax(reinterpret_cast<unsigned int*>(out) + 1, __float_as_uint(fabsf(bias[row])));
+    }
+}
+
+int launch_rows_norm_max(const void* W, int dt, int ld, const float* bias, int rows, int K, float* out, hipStream_t s) {
+    if (rows < 1 || K % 4 || ld % 4) return 1;
+    const dim3 grid((rows + 3) / 4);
+    if (dt == DT_F32) hipLaunchKernelGGL((rows_norm_max_kernel<DT_F32>), grid, dim3(256), 0, s, W, ld, bias, rows, K, out);
+    else if (dt == DT_F16) hipLaunchKernelGGL((rows_norm_max_kernel<DT_F16>), grid, dim3(256), 0, s, W, ld, bias, rows, K, out);
+    else if (dt == DT_BF16) hipLaunchKernelGGL((rows_norm_max_kernel<DT_BF16>), grid, dim3(256), 0, s, W, ld, bias, rows, K, out);
     else return 1;
     return hipGetLastError() != hipSuccess;
 }

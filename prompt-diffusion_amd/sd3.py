@@ -143,7 +143,9 @@ class SD3Engine:
                  lib_path: Optional[str] = None, fp8: bool = False):
         """fp8 (2-byte modes; BASELINE config #5 "fp8 MFMA"): the projections fed by an AdaLN output -- q/k/v of both
         streams and ff / ff_context net.0 -- take e4m3 operands with one scale per token and per output channel and run on
-        the block-scaled K = 128 MFMA (twice the f16 rate).  Everything else stays in `precision`."""
+        the block-scaled K = 128 MFMA (twice the f16 rate); level 2 (= True) also the feed-forward-out projections, whose
+        input (the GELU output) is stored as e4m3 under a norm bound.  fp8=1: the first group only.  Everything else stays
+        in `precision`."""
         self.cfg = cfg
         self.base = E.Engine(W.TINY, device=device, precision=precision, stream_f32=stream_f32, lib_path=lib_path)
         lib = self.base.lib
@@ -156,11 +158,11 @@ class SD3Engine:
                           cfg.joint_dim, cfg.pooled_dim, cfg.pos_embed_max_size, cfg.cn_pos_embed_max_size,
                           1 if cfg.force_zeros_for_pooled_projection else 0)
         self.base._check(lib.pd_sd3_configure(self.base._h, C.byref(c)))
-        self.fp8 = bool(fp8)
-        if fp8:
+        self.fp8 = 2 if fp8 is True else int(fp8)
+        if self.fp8:
             if precision in ("f32", "f16x2"):
-                raise ValueError("fp8=True needs a 2-byte engine precision (f16 / bf16)")
-            self.base.set_option("sd3_fp8", 1)
+                raise ValueError("fp8 needs a 2-byte engine precision (f16 / bf16)")
+            self.base.set_option("sd3_fp8", self.fp8)
 
     def close(self):
         self.base.close()

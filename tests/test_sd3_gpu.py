@@ -184,22 +184,22 @@ def test_fp8_linear_kernel_against_emulation(M, K, N):
     e.close()
 
 
-@pytest.mark.parametrize("prec", ["f16", "bf16"])
-def test_fp8_option_against_emulating_oracle(sd, prec):
+@pytest.mark.parametrize("prec,level", [("f16", 1), ("f16", 2), ("bf16", 2)])
+def test_fp8_option_against_emulating_oracle(sd, prec, level):
     """Whole evaluation with option sd3_fp8: against the oracle that emulates the e4m3 operands of the same layers the error
     is the 2-byte mode's own (plus rounding-boundary flips of single e4m3 values); against the unquantised oracle it is what
     fp8 operands cost this (random-weight) network."""
-    e = sd3.SD3Engine(CFG, precision=prec, fp8=True)
+    e = sd3.SD3Engine(CFG, precision=prec, fp8=level)
     e.load_state_dict(sd)
     i = inputs(2, 8, 12, 9, seed=71)
     zero = np.zeros_like(i["pooled"])
     got = e.forward(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 0.8)
-    ctl8 = O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], zero, i["cond"], i["pair"], 0.8, fp8=True)
-    ref8 = O.transformer_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], ctl8, fp8=True)
+    ctl8 = O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], zero, i["cond"], i["pair"], 0.8, fp8=level)
+    ref8 = O.transformer_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], ctl8, fp8=level)
     ctl = O.controlnet_forward(sd, CFG, i["x"], i["t"], i["ctx"], zero, i["cond"], i["pair"], 0.8)
     ref = O.transformer_forward(sd, CFG, i["x"], i["t"], i["ctx"], i["pooled"], ctl)
     e8, e32 = relerr(got, ref8), relerr(got, ref)
-    print("%s + fp8: vs emulating oracle %.2e, vs fp32 oracle %.2e (oracle fp8 vs fp32 %.2e)" % (prec, e8, e32, relerr(ref8, ref)))
+    print("%s + fp8 level %d: vs emulating oracle %.2e, vs fp32 oracle %.2e (oracle fp8 vs fp32 %.2e)" % (prec, level, e8, e32, relerr(ref8, ref)))
     assert e8 < 2 * TOL[prec] and e32 < 1.5e-1
     with pytest.raises(ValueError):
         sd3.SD3Engine(CFG, precision="f32", fp8=True)

@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--stream-f32", action="store_true")
-    ap.add_argument("--fp8", action="store_true", help="e4m3 operands for the AdaLN-fed projections (BASELINE config #5)")
+    ap.add_argument("--fp8", type=int, nargs="?", const=2, default=0,
+                    help="e4m3 operands: 1 = the AdaLN-fed projections, 2 (default when given) = also the feed-forward-out projections")
     ap.add_argument("--dump", default=None, help="with --profile: CSV of every profiled launch, and a per-shape table on stderr")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     a = ap.parse_args()
@@ -83,7 +84,7 @@ def main():
     launches = (eng.base.stat("launches") - n0) / a.repeat / a.steps
     Bf = 2 * B if a.guidance > 1 else B
     fl = step_flops(cfg, Bf, (H // 2) ** 2, S)
-    rec = dict(metric="SD3-medium MMDiT + Prompt-Diffusion ControlNet, seconds per image", precision=a.precision + ("+fp8" if a.fp8 else ""), batch=B,
+    rec = dict(metric="SD3-medium MMDiT + Prompt-Diffusion ControlNet, seconds per image", precision=a.precision + ("+fp8" + ("" if a.fp8 == 2 else "(level 1)") if a.fp8 else ""), batch=B,
                latent=[H, H], context_tokens=S, steps=a.steps, cn_layers=a.cn_layers, layers=a.layers, guidance=a.guidance,
                s_per_image=dt / B, images_per_s=B / dt, ms_per_step=1e3 * dt / a.steps, tflops_per_step=fl / 1e12,
                path_tflops_per_s=fl * a.steps / dt / 1e12, launches_per_step=launches,
