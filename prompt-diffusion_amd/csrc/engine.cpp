@@ -681,9 +681,10 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         int splitk = 1;
         // linear layers with a short K and at least half a chip of tiles: one 8-wave block per CU instead of split-K
         const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !fp8 && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
-        if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= 16 && m.N % 4 == 0) {
+        const int kmin = fp8 ? 8 : 16, kper = fp8 ? 4 : 8;   // an e4m3 K step carries twice the K of a 2-byte one
+        if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= kmin && m.N % 4 == 0) {
             splitk = (512 + tiles - 1) / tiles;
-            if (splitk > ktiles / 8) splitk = ktiles / 8;
+            if (splitk > ktiles / kper) splitk = ktiles / kper;
             if (splitk > opt_splitk_max) splitk = opt_splitk_max;
             if (splitk < 1) splitk = 1;
         }
