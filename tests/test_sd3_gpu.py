@@ -189,7 +189,7 @@ def test_fp8_option_against_emulating_oracle(sd, prec, level):
     """Whole evaluation with option sd3_fp8: against the oracle that emulates the e4m3 operands of the same layers the error
     is the 2-byte mode's own (plus rounding-boundary flips of single e4m3 values); against the unquantised oracle it is what
     fp8 operands cost this (random-weight) network."""
-    e = sd3.SD3Engine(CFG, precision=prec, fp8=level)
+    e = sd3.SD3Engine(CFG, precision=prec, fp8=level, stream_f32=(prec == "f16" and level == 2))   # one case on fp32 residual streams
     e.load_state_dict(sd)
     i = inputs(2, 8, 12, 9, seed=71)
     zero = np.zeros_like(i["pooled"])
