@@ -274,6 +274,9 @@ int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, i
 // max over rows of the row L2 norm of W (dtype dt, row stride ld) and max |bias| -> out[0], out[1] (fp32, device, zeroed by the caller)
 int launch_rows_norm_max(const void* W, int dt, int ld, const float* bias, int rows, int K, float* out, hipStream_t s);
 int launch_patchify(const float* nchw, void* out, int out_dt, int B, int C, int H, int W, int patch, int Cpad, int Kpad, hipStream_t s);
+// Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0) of B <= 64 host-side timesteps: out[b] = [cos(t f_i) | sin(t f_i)],
+// f_i = exp(-ln(10000) i / 128); the values are passed by value (no host buffer has to outlive the launch)
+int launch_timestep_embedding(const float* t_host, int B, float* out, hipStream_t s);
 int launch_pos_crop(const float* table, float* out, int B, int h, int w, int max_size, int D, hipStream_t s);
 int launch_unpatchify(const void* in, int in_dt, int ld, float* nchw, int B, int C, int h, int w, int patch, hipStream_t s);
 int launch_cfg_euler(const float* v, float* x, int B, long long n, float guidance, float dsigma, int use_cfg, hipStream_t s);

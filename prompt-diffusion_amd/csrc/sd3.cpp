@@ -92,18 +92,6 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
     net.built = true;
 }
 
-// Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
-static void sd3_sinusoid(const float* t, int B, std::vector<float>& out) {
-    out.resize((size_t)B * 256);
-    for (int b = 0; b < B; ++b)
-        for (int i = 0; i < 128; ++i) {
-            const float f = std::exp(-std::log(10000.0f) * (float)i / 128.0f);
-            const float a = t[b] * f;
-            out[(size_t)b * 256 + i] = std::cos(a);
-            out[(size_t)b * 256 + 128 + i] = std::sin(a);
-        }
-}
-
 // patch embedding (+ ControlNet condition embeddings), temb, context embedding, modulation vectors
 int pd_engine::sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs, Act& c, Act& modbuf) {
     const int D = sd3.heads * sd3.head_dim, ps = sd3.patch_size, h = io.H / ps, w = io.W / ps, N = h * w, B = io.B;
@@ -145,10 +133,11 @@ int pd_engine::sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs
     Act pooled = new_act(B, 1, 1, round_up(sd3.pooled_dim, 8), DT_F32);
     Act u = new_act(B, 1, 1, D, DT_F32), temb = new_act(B, 1, 1, D, DT_F32);
     if (!arena.dry) {
-        std::vector<float> sv;
-        sd3_sinusoid(io.t_host, B, sv);
-        HIP_OK(hipMemcpyAsync(sin_t.p, sv.data(), sv.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-        HIP_OK(hipStreamSynchronize(stream));   // sv is pageable host memory
+        ++launches;
+        if (launch_timestep_embedding(io.t_host, B, reinterpret_cast<float*>(sin_t.p), stream)) {   // timesteps travel as kernel arguments
+            pd_set_error("sd3: timestep embedding launch failed (batch %d)", B);
+            return 1;
+        }
         HIP_OK(hipMemsetAsync(pooled.p, 0, pooled.bytes(), stream));
         const float* src = controlnet ? io.cn_pooled : io.pooled;   // ControlNet: null = zero pooled projections
         if (src)
@@ -445,6 +434,7 @@ int sd3_check(pd_engine* e, const pd_sd3_args* a, bool need_cond) {
     for (auto& p : e->params)
         if (p.group == 3 && !p.loaded) { pd_set_error("SD3 weights not loaded: '%s' (and possibly more)", p.name.c_str()); return 1; }
     const int ps = e->sd3.patch_size;
+    if (a->batch > 32) { pd_set_error("pd_sd3: batch %d exceeds 32 per call (the guided loop doubles it; shard larger batches)", a->batch); return 1; }
     if (a->batch < 1 || a->height < ps || a->width < ps || a->height % ps || a->width % ps || a->context_len < 1) {
         pd_set_error("pd_sd3: bad shape (batch %d, latent %dx%d, patch %d, context_len %d)", a->batch, a->height, a->width, ps, a->context_len);
         return 1;

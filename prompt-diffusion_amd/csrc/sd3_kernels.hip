@@ -398,3 +398,20 @@ int launch_rows_norm_max(const void* W, int dt, int ld, const float* bias, int r
     else return 1;
     return hipGetLastError() != hipSuccess;
 }
+
+struct TimestepArgs { float t[64]; };
+__global__ __launch_bounds__(128) void timestep_embedding_kernel(TimestepArgs a, float* __restrict__ out) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    const float f = expf(-logf(10000.0f) * (float)i / 128.0f);
+    const float x = a.t[b] * f;
+    out[(size_t)b * 256 + i] = cosf(x);
+    out[(size_t)b * 256 + 128 + i] = sinf(x);
+}
+
+int launch_timestep_embedding(const float* t_host, int B, float* out, hipStream_t s) {
+    if (B < 1 || B > 64) return 1;
+    TimestepArgs a{};
+    for (int b = 0; b < B; ++b) a.t[b] = t_host[b];
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(B), dim3(128), 0, s, a, out);
+    return hipGetLastError() != hipSuccess;
+}
