@@ -110,3 +110,35 @@ def test_struct_layout_matches_header():
     assert C.sizeof(sd3.pd_sd3_config) == 16 * 4
     assert C.sizeof(sd3.pd_sd3_args) == 6 * 4 + 7 * 8 + 3 * 8
     assert sd3.pd_sd3_args.latents.offset == 24 and sd3.pd_sd3_args.pair.offset == 64 and sd3.pd_sd3_args.cn_pooled.offset == 72
+
+
+def test_pipeline_host_logic_without_a_gpu():
+    """The SD3 pipeline mirror's host pieces that need no engine: check_inputs errors, the sigma grid, image / latent
+    preparation (promptdiffusioncontrolnetpipeline_sd3.py:541-698, :1129-1146)."""
+    from prompt_diffusion_amd.pipeline_sd3 import StableDiffusion3PromptDiffusionPipeline as Pipe
+    p = Pipe(None, shift=3.0)
+    e = np.zeros((1, 4, 8), np.float32)
+    with pytest.raises(ValueError, match="divisible by 8"):
+        p.check_inputs(None, None, None, 100, 64, prompt_embeds=e, pooled_prompt_embeds=e)
+    with pytest.raises(ValueError, match="Cannot forward both `prompt_2`"):
+        p.check_inputs(None, "x", None, 64, 64, prompt_embeds=e, pooled_prompt_embeds=e)
+    with pytest.raises(ValueError, match="has to be of type"):
+        p.check_inputs(3, None, None, 64, 64)
+    with pytest.raises(ValueError, match="negative_pooled_prompt_embeds"):
+        p.check_inputs(None, None, None, 64, 64, prompt_embeds=e, pooled_prompt_embeds=e, negative_prompt_embeds=e)
+    p.check_inputs("a", None, None, 64, 64, negative_prompt="b", max_sequence_length=512)
+    sig, n = p._sigmas(5, None)
+    assert n == 5 and np.array_equal(sig, sd3.flow_match_sigmas(5, 3.0))
+    sig, n = p._sigmas(99, [1.0, 0.5])                       # custom sigmas decide the step count, get shifted, end in 0
+    assert n == 2 and np.allclose(sig, [1.0, 3 * 0.5 / 2.0, 0.0])
+    img = p.prepare_image(np.full((16, 16, 3), 0.75, np.float32), batch_size=3, num_images_per_prompt=1)
+    assert img.shape == (3, 3, 16, 16) and np.allclose(img, 0.5)          # HWC in [0, 1] -> NCHW in [-1, 1], repeated per prompt
+    t = p.prepare_image(torch.full((2, 3, 8, 8), -0.25), batch_size=2, num_images_per_prompt=2)
+    assert t.shape == (4, 3, 8, 8) and np.allclose(t, -0.25)              # tensors pass unchanged, repeated per image
+    a = p.prepare_latents(2, 4, 64, 32, np.random.default_rng(0))
+    b = p.prepare_latents(2, 4, 64, 32, np.random.default_rng(0))
+    assert a.shape == (2, 4, 8, 4) and np.array_equal(a, b)
+    g = p.prepare_latents(1, 4, 64, 32, torch.Generator().manual_seed(3))
+    assert np.array_equal(g, torch.randn((1, 4, 8, 4), generator=torch.Generator().manual_seed(3)).numpy())
+    with pytest.raises(ValueError, match="list of generators"):
+        p.prepare_latents(2, 4, 64, 32, [np.random.default_rng(0)])
