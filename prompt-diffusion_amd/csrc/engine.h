@@ -327,6 +327,7 @@ struct pd_engine {
     // SD3 / MMDiT path (sd3.cpp)
     pd_sd3_config sd3{};
     Sd3NetW sd3_tr, sd3_cn;
+    std::vector<hipEvent_t> sd3_ev;   // ControlNet residual i written (recorded on the second stream)
     struct Sd3Io {   // device pointers of one evaluation
         const float *latents, *context, *pooled, *cond, *pair;
         const float* cn_pooled;   // ControlNet's pooled projections; null: zeros

@@ -306,35 +306,57 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
     const int D = sd3.heads * sd3.head_dim, ps = sd3.patch_size, h = io.H / ps, w = io.W / ps, N = h * w, B = io.B;
     const size_t mk0 = arena.mark();
     std::vector<Act> control;
-    if (io.cond && (io.scale != 0.f || control_index >= 0)) {   // scale 0 (controlnet_keep): every residual is zero
+    // The ControlNet runs on the second stream with its own workspace (like the UNet path's, engine.cpp forward_eps): the
+    // transformer needs residual j only after its block j * interval, so all but the first ControlNet block overlap
+    // transformer work -- the two streams fill each other's tails (attention runs 2.2 rounds of blocks) and small launches.
+    const bool have_cn = io.cond && (io.scale != 0.f || control_index >= 0);
+    const bool two = have_cn && opt_two_streams && stream2 != nullptr && control_index < 0;
+    if (have_cn) {
         Sd3NetW& net = sd3_cn;
         for (int i = 0; i < net.layers; ++i) control.push_back(new_act(B, N, 1, D, control_index >= 0 ? DT_F32 : S));
-        const size_t mk = arena.mark();
-        Act hs, c, modbuf, qk, vt;
-        PD_TRY(sd3_embed(net, io, true, hs, c, modbuf));
-        {
-            const int Nt = N + io.S, vt_ld = round_up(Nt, 8);
-            qk = new_act(B, Nt, 1, 2 * D, T);
-            vt = new_act(B, D, 1, vt_ld, T);
-            if (!arena.dry && vt_ld != Nt) HIP_OK(hipMemsetAsync(vt.p, 0, vt.bytes(), stream));   // pad keys of V^T must read as 0
+        if (two && !arena.dry) {
+            while ((int)sd3_ev.size() < net.layers) {
+                hipEvent_t ev = nullptr;
+                HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                sd3_ev.push_back(ev);
+            }
+            HIP_OK(hipEventRecord(ev_fork, stream));
+            HIP_OK(hipStreamWaitEvent(stream2, ev_fork, 0));
         }
-        for (int i = 0; i < net.layers; ++i) {
-            PD_TRY(sd3_block(net.blocks[i], hs, c, modbuf, qk, vt));
-            // controlnet_blocks[i](hidden_states) * conditioning_scale   (:469-474)
-            Act in = hs;
-            if (hs.dt != T) {   // stream_f32: the zero Linear reads 2-byte operands
-                in = new_act(B, N, 1, D, T);
-                if (!arena.dry) {
-                    ++launches;
-                    if (launch_cast_rows(reinterpret_cast<const float*>(hs.p), in.p, T, (long long)B * N, D, D, stream)) {
-                        pd_set_error("sd3: cast launch failed");
-                        return 1;
+        if (two) swap_context();
+        auto body = [&]() -> int {
+            const size_t mk = arena.mark();
+            Act hs, c, modbuf, qk, vt;
+            PD_TRY(sd3_embed(net, io, true, hs, c, modbuf));
+            {
+                const int Nt = N + io.S, vt_ld = round_up(Nt, 8);
+                qk = new_act(B, Nt, 1, 2 * D, T);
+                vt = new_act(B, D, 1, vt_ld, T);
+                if (!arena.dry && vt_ld != Nt) HIP_OK(hipMemsetAsync(vt.p, 0, vt.bytes(), stream));   // pad keys of V^T must read as 0
+            }
+            for (int i = 0; i < net.layers; ++i) {
+                PD_TRY(sd3_block(net.blocks[i], hs, c, modbuf, qk, vt));
+                // controlnet_blocks[i](hidden_states) * conditioning_scale   (:469-474)
+                Act in = hs;
+                if (hs.dt != T) {   // stream_f32: the zero Linear reads 2-byte operands
+                    in = new_act(B, N, 1, D, T);
+                    if (!arena.dry) {
+                        ++launches;
+                        if (launch_cast_rows(reinterpret_cast<const float*>(hs.p), in.p, T, (long long)B * N, D, D, stream)) {
+                            pd_set_error("sd3: cast launch failed");
+                            return 1;
+                        }
                     }
                 }
+                PD_TRY(gemm(net.zero[i], in, control[i], 1, 0, 0, io.scale, nullptr, nullptr, 0, false, nullptr, 0, 0));
+                if (two && !arena.dry) HIP_OK(hipEventRecord(sd3_ev[i], stream));   // residual i is ready (`stream` is stream2 here)
             }
-            PD_TRY(gemm(net.zero[i], in, control[i], 1, 0, 0, io.scale, nullptr, nullptr, 0, false, nullptr, 0, 0));
-        }
-        arena.release(mk);
+            arena.release(mk);
+            return 0;
+        };
+        const int rc = body();
+        if (two) swap_context();
+        if (rc) return rc;
     }
     if (control_index >= 0) {
         if (control_index >= (int)control.size()) { pd_set_error("sd3: control index %d out of range", control_index); return 1; }
@@ -356,9 +378,14 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
     // hidden_states + block_controlnet_hidden_states[i // interval] after block i (every block but the last): the add rides
     // on the next block's first AdaLN pass
     const Act* pending = nullptr;
+    int waited = -1;   // last ControlNet residual this stream has waited for
     for (int i = 0; i < net.layers; ++i) {
         PD_TRY(sd3_block(net.blocks[i], hs, c, modbuf, qk, vt, pending));
         pending = (interval && !net.blocks[i].pre_only) ? &control[i / interval] : nullptr;
+        if (pending && two && !arena.dry && i / interval > waited) {
+            waited = i / interval;
+            HIP_OK(hipStreamWaitEvent(stream, sd3_ev[waited], 0));
+        }
     }
     // norm_out (AdaLayerNormContinuous: scale, shift) + proj_out + unpatchify
     Act nx = new_act(B, N, 1, D, T);
@@ -474,14 +501,28 @@ int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, 
     io.t_host = t_host.data();
     io.cond = a->cond; io.pair = a->pair;   // non-null markers for the dry run
     io.scale = 1.f;                         // ... which always counts the ControlNet (a per-step scale may switch it on)
-    Arena saved = e->arena;
+    Arena saved = e->arena, saved2 = e->arena2;
     e->arena.base = nullptr; e->arena.cap = 0; e->arena.top = 0; e->arena.peak = 0; e->arena.dry = true; e->arena.overflow = false;
+    e->arena2 = e->arena;
     int r = e->sd3_forward(io, nullptr, control_index, nullptr);
     const size_t staged = (n_lat * 8 + n_ctx + 2 * n_pool + n_v + n_out) * sizeof(float) + 16 * 256;
     const size_t need = e->arena.peak + staged + (64u << 20);
+    const size_t need2 = e->arena2.peak ? e->arena2.peak + (16u << 20) : 0;   // the ControlNet stream's workspace
     e->arena = saved;
+    e->arena2 = saved2;
     e->arena.dry = false;
     if (r) return r;
+    if (need2 > e->arena2.cap) {
+        hipStreamSynchronize(e->stream);
+        if (e->stream2) hipStreamSynchronize(e->stream2);
+        e->clear_graphs();
+        if (e->arena2.base) hipFree(e->arena2.base);
+        e->arena2.base = nullptr; e->arena2.cap = 0;
+        void* p2 = nullptr;
+        if (hipMalloc(&p2, need2) != hipSuccess) { pd_set_error("SD3 ControlNet workspace allocation of %.2f GiB failed", (double)need2 / (1 << 30)); return 1; }
+        e->arena2.base = reinterpret_cast<char*>(p2); e->arena2.cap = need2;
+    }
+    e->arena2.top = 0; e->arena2.peak = 0; e->arena2.overflow = false;
     if (need > e->arena.cap) {
         hipStreamSynchronize(e->stream);
         if (e->stream2) hipStreamSynchronize(e->stream2);
@@ -548,7 +589,10 @@ int sd3_run(pd_engine* e, const pd_sd3_args* a, const float* sigmas, int steps, 
         }
     }
     if (!r) r = e->check_arena();
+    if (e->stream2 && hipStreamSynchronize(e->stream2) != hipSuccess && !r) { pd_set_error("second stream failed"); r = 1; }
+    if (e->arena2.overflow && !r) { pd_set_error("SD3 ControlNet workspace overflow"); r = 1; }
     e->arena.top = 0;
+    e->arena2.top = 0;
     return r;
 }
 }  // namespace

@@ -467,6 +467,7 @@ void pd_engine_destroy(pd_engine* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     e->clear_graphs();
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
+    for (hipEvent_t ev : e->sd3_ev) hipEventDestroy(ev);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->arena2.base) hipFree(e->arena2.base);
