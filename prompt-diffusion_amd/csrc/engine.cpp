@@ -712,7 +712,6 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
             ((p.M + 255) / 256) * (m.N / 192) >= 192)
             p.big_tile = 4;
         if (P == PREC_F16X2 && m.geglu && p.big_tile == 3) p.big_tile = 1;   // the 256 x 320 GEGLU tile spills with the split-operand fragments
-        if (splitk == 1) p.tile_gn = opt_tile_gn;   // wide layers: super-tile order inside each XCD's run of tiles (the kernel checks divisibility)
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
         if (ln_out && splitk == 1 && !m.geglu && !VT) {   // this launch's own epilogue leaves the row statistics
             const int bn_cols = p.big_tile == 3 ? 320 : p.big_tile == 4 ? 192 : 160;

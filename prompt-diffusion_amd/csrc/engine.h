@@ -281,7 +281,6 @@ struct pd_engine {
     int opt_patch_split_fill = 256;   // slices are chosen to reach about this many blocks
     int opt_dense_k = 40;      // linear layers with at most this many K steps and >= opt_dense_tiles tiles: one 8-wave block per CU, no split-K
     bool opt_bigtile = true;  // 256-row GEMM tiles where the grid still fills the chip
-    int opt_tile_gn = 0;      // GEMM tile order: 4 x G super-tiles inside an XCD run for layers at least 2G tiles wide (0: off; G = 8 measured neutral)
     bool opt_tile192 = true;  // 256 x 192 GEMM tiles for widths that divide by 192 but not by 160 (MMDiT)
     // apply GroupNorm(+SiLU) inside the patch conv's staging.  Measured neutral-to-negative in round 1 (the SiLU VALU work
     // lands on the MFMA waves and the halo is transformed 1.27x redundantly), so it is off by default.

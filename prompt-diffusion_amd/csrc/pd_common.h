@@ -201,10 +201,6 @@ struct GemmParams {
     // c_dt == DT_FP8 (MM instantiations): the output rows are written as e4m3 of value / c_scale[row]; the caller guarantees
     // |value| <= 448 c_scale[row] (sd3.cpp: a Cauchy-Schwarz bound from the input row's norm)
     const float* c_scale;
-    // tile order (igemm_kernel): 0 = an XCD's run of tiles is n-fastest over whole rows of tiles; G > 0 = the run is cut into
-    // super-tiles of 4 x G tiles (m x n), so the ~32 blocks an XCD has in flight share 4 A panels and G weight panels instead
-    // of ~1 A panel and every weight panel of a wide layer (fabric -> L2 traffic per K step ~2-3x lower for N >= 16 tiles)
-    int tile_gn;
 };
 
 // element-wise / norm / attention launchers (definitions in the .hip files)

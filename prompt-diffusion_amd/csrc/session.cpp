@@ -735,7 +735,6 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "dense_tiles")) { e->opt_dense_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_k")) { e->opt_dense_k = (int)value; return 0; }
     if (!strcmp(key, "big_tile")) { e->opt_bigtile = value != 0; return 0; }
-    if (!strcmp(key, "tile_gn")) { e->opt_tile_gn = (int)value; return 0; }
     if (!strcmp(key, "tile192")) { e->opt_tile192 = value != 0; return 0; }
     if (!strcmp(key, "gemv")) { e->opt_gemv = value != 0; return 0; }
     if (!strcmp(key, "sd3_fp8")) { e->opt_sd3_fp8 = (int)value; e->sd3_fp8_dirty = true; return 0; }
