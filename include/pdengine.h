@@ -197,7 +197,12 @@ int pd_wait_stream(pd_engine* e, void* producer);
  *   "big_tile" / "wide_tile" (256x160 / 256x320 GEMM tiles, 1), "dense_k" / "dense_tiles" (8-wave unsplit tile for
  *   linear layers with at most that many K steps, 40 / 128), "short_k" (8-wave 128x160 tile at 16 waves per CU for
  *   linear layers with at most that many K steps, 20), "splitk_tiles" (split K below this many tiles, 384),
- *   "splitk_fused" (in-kernel split-K finalize, 0),
+ *   "splitk_fused" (in-kernel split-K finalize, 0), "tile192" (256x192 GEMM tile for widths that divide by 192 but not by
+ *   160: the MMDiT's 1536 / 4608 / 6144, 1), "gemv" (weight-streaming kernel for a Linear over <= 4 fp32 rows with >= 4096
+ *   outputs: the MMDiT modulation matrix, 1),
+ *   "sd3_fp8" (SD3 path, 2-byte modes: 0 off; 1 the projections fed by an AdaLN output -- q/k/v of both streams, ff / ff_context
+ *   net.0 -- take e4m3 operands with one scale per token and per output channel on the block-scaled K = 128 MFMA; 2 also the
+ *   feed-forward-out projections, their input stored as e4m3 under a row bound; default 0),
  *   "attn_legacy" (single-buffered attention kernel, 0). */
 int pd_set_option(pd_engine* e, const char* key, int64_t value);
 int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches", "steps", "event_overhead_ns" */
@@ -256,7 +261,7 @@ typedef struct pd_sd3_config {
 } pd_sd3_config;
 
 typedef struct pd_sd3_args {
-    int32_t batch;            /* B: rows of every tensor below */
+    int32_t batch;            /* B: rows of every tensor below (<= 32 per call) */
     int32_t height, width;    /* latent size (multiples of patch_size) */
     int32_t context_len;      /* S tokens of `context` */
     int32_t mem;              /* PD_MEM_HOST / PD_MEM_DEVICE of all tensor pointers (timestep is always host) */

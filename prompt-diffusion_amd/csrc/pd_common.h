@@ -170,7 +170,7 @@ struct GemmParams {
     int splitk;           // >1: grid.y slices K; each slice stores an fp32 slab, a finalize pass sums them + epilogue
     void* slab;           // [splitk][M][N] fp32 workspace
     int* tile_cnt;        // split-K: one zeroed counter per 128x160 tile -> finalize fused into the last-arriving slice; null: separate pass
-    int big_tile;         // 1: 256 x 160 block tile (8 waves) instead of 128 x 160
+    int big_tile;         // tile: 0 128 x 160 (4 waves), 1 256 x 160, 2 128 x 160 on 8 waves (short K), 3 256 x 320, 4 256 x 192
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;
     int ldw;              // weight row stride in elements (0: Kpad) -- lets a device activation act as the W operand
