@@ -11,7 +11,7 @@ Fig. 2 / Sec. 4) under the reference's own call sites and parameter names:
     pos_embed_input(example pair), joint blocks, one zero Linear per block, * conditioning_scale
   * transformer forward consumed as self.transformer(hidden_states, timestep, encoder_hidden_states, pooled_projections,
     block_controlnet_hidden_states) (pipeline :1226-1234); residual i is added after block i with
-    interval = ceil(len(blocks) / len(residuals))
+    interval_control = len(blocks) / len(residuals) (a float; index int(i / interval_control))
   * CFG uncond + s (text - uncond) (:1237-1239) and latents + (sigma_next - sigma) * v (scheduler.step, :1243)
 The engine path (csrc/sd3.cpp) is tested against THIS file only (tests/test_sd3_gpu.py)."""
 import math
@@ -211,12 +211,12 @@ def transformer_forward(sd, cfg, x, t, ctx, pooled, control=None, prefix="transf
     hs = (hs + cropped_pos_embed(P("pos_embed.pos_embed")[0], cfg.pos_embed_max_size, h, w)[None]).astype(F32)
     temb = time_text_embed(sd, prefix + "time_text_embed.", t, pooled)
     c = linear(ctx, P("context_embedder.weight"), P("context_embedder.bias"))
-    interval = int(math.ceil(cfg.layers / len(control))) if control else 0
+    interval_control = cfg.layers / len(control) if control else 0.0     # float division, as SD3Transformer2DModel.forward does
     for i in range(cfg.layers):
         last = i == cfg.layers - 1
         c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, last, fp8)
         if control and not last:
-            hs = (hs + control[i // interval]).astype(F32)
+            hs = (hs + control[int(i / interval_control)]).astype(F32)
     m = linear(silu(temb), P("norm_out.linear.weight"), P("norm_out.linear.bias"))
     sc, sh = np.split(m, 2, axis=-1)
     hs = layer_norm_noaffine(hs) * (1 + sc[:, None]) + sh[:, None]

@@ -307,7 +307,7 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
     const size_t mk0 = arena.mark();
     std::vector<Act> control;
     // The ControlNet runs on the second stream with its own workspace (like the UNet path's, engine.cpp forward_eps): the
-    // transformer needs residual j only after its block j * interval, so all but the first ControlNet block overlap
+    // transformer needs residual j only after its block ~ j * layers / residuals, so all but the first ControlNet block overlap
     // transformer work -- the two streams fill each other's tails (attention runs 2.2 rounds of blocks) and small launches.
     const bool have_cn = io.cond && (io.scale != 0.f || control_index >= 0);
     const bool two = have_cn && opt_two_streams && stream2 != nullptr && control_index < 0;
@@ -374,16 +374,19 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
         vt = new_act(B, D, 1, vt_ld, T);
         if (!arena.dry && vt_ld != Nt) HIP_OK(hipMemsetAsync(vt.p, 0, vt.bytes(), stream));   // pad keys of V^T must read as 0
     }
-    const int interval = control.empty() ? 0 : (net.layers + (int)control.size() - 1) / (int)control.size();
-    // hidden_states + block_controlnet_hidden_states[i // interval] after block i (every block but the last): the add rides
-    // on the next block's first AdaLN pass
+    // hidden_states + block_controlnet_hidden_states[int(i / interval_control)] after block i (every block but the
+    // context_pre_only last one), interval_control = len(blocks) / len(residuals) as a FLOAT (SD3Transformer2DModel.forward;
+    // it is the Flux transformer that takes the ceiling): 18 residuals on 24 blocks map 0,0,1,2,3,3,4,5,...  The add rides
+    // on the next block's first AdaLN pass.
+    const bool steer = !control.empty();
+    auto ctl_index = [&](int i) { return (int)((double)i / ((double)net.layers / (double)control.size())); };
     const Act* pending = nullptr;
     int waited = -1;   // last ControlNet residual this stream has waited for
     for (int i = 0; i < net.layers; ++i) {
         PD_TRY(sd3_block(net.blocks[i], hs, c, modbuf, qk, vt, pending));
-        pending = (interval && !net.blocks[i].pre_only) ? &control[i / interval] : nullptr;
-        if (pending && two && !arena.dry && i / interval > waited) {
-            waited = i / interval;
+        pending = (steer && !net.blocks[i].pre_only) ? &control[ctl_index(i)] : nullptr;
+        if (pending && two && !arena.dry && ctl_index(i) > waited) {
+            waited = ctl_index(i);
             HIP_OK(hipStreamWaitEvent(stream, sd3_ev[waited], 0));
         }
     }

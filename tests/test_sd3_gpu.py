@@ -67,6 +67,21 @@ def test_controlnet_residuals_and_steered_velocity(eng, sd, B, H, W, S):
     assert relerr(plain, ref) > 10 * TOL[eng.prec] or eng.prec == "bf16"    # the residuals do steer this network
 
 
+def test_non_divisible_residual_mapping():
+    """5 transformer blocks, 4 ControlNet blocks: residual int(i / 1.25) after block i (0, 0, 1, 2) -- the float interval of
+    SD3Transformer2DModel.forward, where a ceiling would give 0, 0, 1, 1."""
+    import dataclasses
+    cfg = dataclasses.replace(CFG, layers=5, cn_layers=4)
+    w = sd3.synth_sd3_state_dict(cfg)
+    e = sd3.SD3Engine(cfg, precision="f32")
+    e.load_state_dict(w)
+    i = inputs(2, 8, 8, 6, seed=81, cfg=cfg)
+    ctl = O.controlnet_forward(w, cfg, i["x"], i["t"], i["ctx"], 0 * i["pooled"], i["cond"], i["pair"])
+    ref = O.transformer_forward(w, cfg, i["x"], i["t"], i["ctx"], i["pooled"], ctl)
+    assert relerr(e.forward(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"]), ref) < 2e-4
+    e.close()
+
+
 def test_sampling_loop_with_guidance(eng, sd):
     B, H, W, S, steps = 1, 8, 8, 7, 3
     i, n = inputs(B, H, W, S, seed=21), inputs(B, H, W, S, seed=22)

@@ -84,10 +84,32 @@ def test_zero_initialised_controlnet_is_a_no_op():
     c2 = O.controlnet_forward(sd, CFG, x, t, ctx, pooled, cond, pair, 0.5)
     assert all(np.allclose(a * 0.5, b, atol=1e-6) for a, b in zip(c1, c2))
     assert np.abs(O.transformer_forward(sd, CFG, x, t, ctx, pooled, c1) - plain).max() > 1e-2
-    # residual i lands after block i // ceil(layers / len(residuals)) -- one residual for all blocks == the same one repeated
+    # residual int(i / (layers / len(residuals))) lands after block i -- one residual for all blocks == the same one repeated
     one = O.transformer_forward(sd, CFG, x, t, ctx, pooled, c1[:1])
     rep = O.transformer_forward(sd, CFG, x, t, ctx, pooled, [c1[0], c1[0], c1[0]])
     assert np.allclose(one, rep, atol=1e-6)
+
+
+def test_residual_to_block_mapping_is_the_float_interval():
+    """SD3Transformer2DModel.forward indexes the residuals with int(i / (len(blocks) / len(residuals))) -- a float interval,
+    not the ceiling the Flux transformer takes.  5 blocks (the last context_pre_only) and 4 residuals: blocks 0..3 get
+    residuals 0, 0, 1, 2 (the ceiling would give 0, 0, 1, 1), and residual 3 is never used."""
+    import dataclasses
+    cfg = dataclasses.replace(CFG, layers=5, cn_layers=4)
+    sd = sd3.synth_sd3_state_dict(cfg)
+    rng = np.random.default_rng(5)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    x, ctx, pooled = f(1, 4, 8, 8), f(1, 3, cfg.joint_dim), f(1, cfg.pooled_dim)
+    t = np.array([400.0], np.float32)
+    ctl = [f(1, 16, cfg.hidden) for _ in range(4)]
+    base = O.transformer_forward(sd, cfg, x, t, ctx, pooled, ctl)
+    for j, used in ((3, False), (2, True), (1, True), (0, True)):
+        alt = list(ctl)
+        alt[j] = alt[j] + f(1, 16, cfg.hidden)      # (a constant shift would vanish in the next LayerNorm)
+        changed = np.abs(O.transformer_forward(sd, cfg, x, t, ctx, pooled, alt) - base).max() > 1e-3
+        assert changed == used, j
+    # residual 2 enters after block 3 only: identical hidden states up to there means equal outputs when blocks 0-2 ignore it
+    assert [int(i / (5 / 4)) for i in range(4)] == [0, 0, 1, 2]
 
 
 def test_guidance_identities():
