@@ -87,3 +87,30 @@ def test_sampling_loop_identities(eng):
     # guidance on with different negative embeddings does change the result
     c = eng.sample(i["x"], i["ctx"], i["pooled"], i["nctx"], i["npooled"], guidance_scale=6.0, **kw).cpu().numpy()
     assert relerr(c, b) > 1e-2
+
+
+def test_fp8_option_at_the_benchmarked_size():
+    """1024 x 1024 (4096 image + 333 context tokens, the size tools/sd3_bench.py and bench.py's SD3 leg time): one evaluation
+    with e4m3 operands (levels 1 and 2) against the plain f16 mode on the same random weights -- what fp8 operands cost one
+    velocity evaluation at full depth -- plus finiteness and determinism of a guided 2-step sampling."""
+    import torch
+    cfg = sd3.SD3Config(pos_embed_max_size=96)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    f = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x, cond, pair = f(1, 16, 128, 128), f(1, 16, 128, 128), f(1, 16, 128, 128)
+    ctx, nctx, pooled, npooled = f(1, S, cfg.joint_dim), f(1, S, cfg.joint_dim), f(1, cfg.pooled_dim), f(1, cfg.pooled_dim)
+    t = np.array([500.0], np.float32)
+    outs = {}
+    for level in (0, 1, 2):
+        e = sd3.SD3Engine(cfg, precision="f16", fp8=level)
+        e.init_random_weights(11)
+        outs[level] = e.forward(x, t, ctx, pooled, cond, pair).cpu().numpy()
+        if level == 2:
+            kw = dict(control_latents=cond, pair_latents=pair, num_inference_steps=2, guidance_scale=5.0)
+            a = e.sample(x, ctx, pooled, nctx, npooled, **kw).cpu().numpy()
+            b = e.sample(x, ctx, pooled, nctx, npooled, **kw).cpu().numpy()
+            assert np.isfinite(a).all() and np.array_equal(a, b)      # two streams, same result every time
+        e.close()
+    e1, e2 = relerr(outs[1], outs[0]), relerr(outs[2], outs[0])
+    print("SD3-medium at 4096 + 333 tokens, fp8 vs f16 velocity: level 1 %.2e, level 2 %.2e" % (e1, e2))
+    assert np.isfinite(outs[2]).all() and e1 < 3e-2 and e2 < 3e-2      # measured 6.3e-3 / 8.8e-3
