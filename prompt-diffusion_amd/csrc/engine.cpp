@@ -714,8 +714,15 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         if (P == PREC_F16X2 && m.geglu && p.big_tile == 3) p.big_tile = 1;   // the 256 x 320 GEGLU tile spills with the split-operand fragments
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
         if (ln_out && splitk == 1 && !m.geglu && !VT) {   // this launch's own epilogue leaves the row statistics
-            const int bn_cols = p.big_tile == 3 ? 320 : p.big_tile == 4 ? 192 : 160;
+            // the tile launch_prec (gemm.hip) takes for this launch: 256 x 320 only for linear layers over operands of the compute
+            // type, otherwise big_tile 3 falls back to 256 x 160; launch_one rejects a part count that disagrees with its tile
+            const bool wide = p.big_tile == 3 && m.taps == 1 && in.dt == T;
+            const int bn_cols = wide ? 320 : p.big_tile == 4 ? 192 : 160;
             ln_out->parts = ((m.N + bn_cols - 1) / bn_cols) * 2;   // 2 waves across N in every non-GEGLU tile
+            if (ln_out->cap_parts && ln_out->parts > ln_out->cap_parts) {
+                pd_set_error("internal: %d LayerNorm statistics partials per row, buffer holds %d", ln_out->parts, ln_out->cap_parts);
+                return 1;
+            }
             ln_out->C = m.Nout;
             p.stats_out = ln_out->stats;
             p.stats_parts = ln_out->parts;
@@ -915,7 +922,9 @@ int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& k
     // (fold_layernorms): at most 16 column-range partials per row
     LnStats st0, st1;
     if (fuse) {
-        const size_t cap = (size_t)B * N * 16 * 2 * sizeof(float);
+        // one {sum, sum of squares} pair per row and per 80-column wave range of the narrowest tile (160 columns, 2 waves across)
+        st0.cap_parts = st1.cap_parts = ((C + 159) / 160) * 2;
+        const size_t cap = (size_t)B * N * (size_t)st0.cap_parts * 2 * sizeof(float);
         st0.stats = reinterpret_cast<float*>(arena.alloc(cap));
         st1.stats = reinterpret_cast<float*>(arena.alloc(cap));
     }

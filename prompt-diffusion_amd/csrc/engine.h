@@ -53,6 +53,7 @@ struct LnStats {
     float* stats = nullptr;   // [rows][parts][2] {sum, sum of squares}
     int parts = 0;
     int C = 0;
+    int cap_parts = 0;        // partials per row the buffer holds (producers check it before writing)
 };
 
 struct ConvW {

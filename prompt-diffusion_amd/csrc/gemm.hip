@@ -483,6 +483,7 @@ int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     auto kfn = igemm_kernel<P, BM, BN, WM, WN, CONV, AF32, GG, MM>;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM_BYTES, &attr_done)) return 1;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+    if (p.stats_out && p.stats_parts != ntiles * WN) return 1;   // the caller sized the statistics rows for another tile
     dim3 grid(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, s, p);
     if (hipGetLastError() != hipSuccess) return 1;

@@ -31,6 +31,10 @@ class SD3Config:
     pos_embed_max_size: int = 192
     cn_pos_embed_max_size: int = 0  # 0: same as the transformer's
     force_zeros_for_pooled_projection: bool = True   # the reference class's default (promptdiffusioncontrolnet_sd3.py:108)
+    # constructor arguments of the reference class this engine does not implement (promptdiffusioncontrolnet_sd3.py:104-105):
+    # anything but the defaults is rejected, so an SD3.5-style checkpoint cannot load as a silently different network
+    qk_norm: Optional[str] = None
+    dual_attention_layers: tuple = ()
 
     @property
     def hidden(self) -> int:
@@ -146,6 +150,9 @@ class SD3Engine:
         the block-scaled K = 128 MFMA (twice the f16 rate); level 2 (= True) also the feed-forward-out projections, whose
         input (the GELU output) is stored as e4m3 under a norm bound.  fp8=1: the first group only.  Everything else stays
         in `precision`."""
+        if cfg.qk_norm is not None or tuple(cfg.dual_attention_layers):
+            raise NotImplementedError("qk_norm / dual_attention_layers (SD3.5 blocks, promptdiffusioncontrolnet_sd3.py:104-105, "
+                                      ":140-141) are not built: this engine implements the SD3-medium JointTransformerBlock only")
         self.cfg = cfg
         self.base = E.Engine(W.TINY, device=device, precision=precision, stream_f32=stream_f32, lib_path=lib_path)
         lib = self.base.lib
@@ -170,9 +177,17 @@ class SD3Engine:
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd, strict: bool = True) -> None:
         known = {n for n, _ in self.base.param_names()}
+        unexpected = []
         for name, arr in (sd.items() if isinstance(sd, dict) else sd):
-            if name in known and (name.startswith("transformer.") or name.startswith("controlnet.")):
+            if not (name.startswith("transformer.") or name.startswith("controlnet.")):
+                continue
+            if name in known:
                 self.base.load_tensor(name, arr)
+            else:
+                unexpected.append(name)   # e.g. attn.norm_q / attn2.* of an SD3.5 checkpoint: a different network
+        if strict and unexpected:
+            raise E.PdError(f"{len(unexpected)} unexpected SD3 tensors (first: {unexpected[0]}): the checkpoint describes blocks "
+                            "this engine does not implement (qk_norm / dual_attention_layers?)")
         if strict and self.weights_missing():
             raise E.PdError(f"{self.weights_missing()} SD3 tensors missing after load_state_dict")
 

@@ -56,3 +56,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "pd_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_sd3_rejects_unbuilt_block_variants():
+    """promptdiffusioncontrolnet_sd3.py:104-105: qk_norm / dual_attention_layers select blocks this engine does not build;
+    they must be refused before any engine exists instead of loading as a different network."""
+    import pytest
+    from prompt_diffusion_amd import sd3
+    import dataclasses
+    for kw in ({"qk_norm": "rms_norm"}, {"dual_attention_layers": (0, 1)}):
+        with pytest.raises(NotImplementedError):
+            sd3.SD3Engine(dataclasses.replace(sd3.SD3_TINY, **kw))
