@@ -8,6 +8,7 @@
  *   pd_op_groupnorm  GroupNorm32 (+SiLU)                                           util.py:217-219, attention.py:88-89
  *   pd_op_layernorm  nn.LayerNorm                                                  attention.py:263-265
  *   pd_op_attention  softmax(q k^T dh^-0.5) v, heads from the engine config        attention.py:171-193
+ *   pd_op_spatial_transformer  one SpatialTransformer block of the loaded networks  attention.py:271-275,321-340
  */
 #ifndef PDENGINE_OPS_H
 #define PDENGINE_OPS_H
@@ -26,6 +27,10 @@ int pd_op_groupnorm(pd_engine* e, const float* x, const float* gamma, const floa
                     int silu, float* y);
 int pd_op_layernorm(pd_engine* e, const float* x, const float* gamma, const float* beta, int rows, int C, float* y);
 int pd_op_attention(pd_engine* e, const float* q, const float* k, const float* v, int B, int Nq, int Nk, int C, float* o);
+/* SpatialTransformer.forward of the block whose weights were loaded under `prefix` (reference state-dict prefix ending in '.'),
+ * x [B, C, H, W], context [B, context_len, context_dim], y [B, C, H, W]; the same code path as a sampling step (2-byte modes at
+ * 320 channels: self-attention + the fused tail kernel). */
+int pd_op_spatial_transformer(pd_engine* e, const char* prefix, const float* x, const float* context, int B, int H, int W, float* y);
 #ifdef __cplusplus
 }
 #endif

@@ -529,25 +529,47 @@ int pd_engine::init_random(uint64_t seed) {
 // LayerNorm folded into its consumer (attention.py:271-275: x + attn1(norm1(x)), + attn2(norm2(x)), + ff(norm3(x))):
 // LN(x) . W^T = rstd * (x . (W diag(gamma))^T - mean * colsum) + beta . W^T, so the consumer GEMM reads the residual stream
 // itself and the normalised tensor is never written.  Built once per weight change.
+bool pd_engine::st_tail_on(const STW& s, int rows_per_sample) const {
+    return opt_st_fuse && S == T && st_tail_eligible(P, s.C, cfg.num_heads, rows_per_sample, cfg.context_len);
+}
+
 int pd_engine::fold_layernorms() {
     const bool on = opt_ln_fuse < 0 ? !f32 : opt_ln_fuse != 0;
-    if (!on || !ln_dirty) return 0;
+    const bool tail = opt_st_fuse && S == T && (P == DT_F16 || P == DT_BF16);
+    if ((!on && !tail) || !ln_dirty) return 0;
+    auto fold = [&](WMat& m, const float* g, const float* b) -> int {
+        if (!m.w_ln) {
+            m.w_ln = dmalloc((size_t)m.N * m.Kpad * dt_size(T));
+            m.colsum = reinterpret_cast<float*>(dmalloc((size_t)(m.N + 4) * sizeof(float)));
+            m.bias_ln = reinterpret_cast<float*>(dmalloc((size_t)(m.N + 4) * sizeof(float)));
+            if (!m.w_ln || !m.colsum || !m.bias_ln) { pd_set_error("allocation of folded LayerNorm weights failed"); return 1; }
+        }
+        if (launch_ln_fold(m.w, m.w_ln, T, m.N, m.K, m.Kpad, g, b, m.bias, m.colsum, m.bias_ln, stream)) {
+            pd_set_error("LayerNorm fold launch failed");
+            return 1;
+        }
+        return 0;
+    };
     for (int which = 0; which < 2; ++which) {
         NetW& net = which ? cnet : unet;
         for (STW* st : net.st_list) {
-            WMat* mats[2] = {&st->qkv, &st->q2};   // norm1 -> to_q/k/v, norm2 -> attn2.to_q; norm3 (GEGLU tile) stays a kernel
-            for (int i = 0; i < 2; ++i) {
-                WMat& m = *mats[i];
-                if (!m.w_ln) {
-                    m.w_ln = dmalloc((size_t)m.N * m.Kpad * dt_size(T));
-                    m.colsum = reinterpret_cast<float*>(dmalloc((size_t)(m.N + 4) * sizeof(float)));
-                    m.bias_ln = reinterpret_cast<float*>(dmalloc((size_t)(m.N + 4) * sizeof(float)));
-                    if (!m.w_ln || !m.colsum || !m.bias_ln) { pd_set_error("allocation of folded LayerNorm weights failed"); return 1; }
-                }
-                if (launch_ln_fold(m.w, m.w_ln, T, m.N, m.K, m.Kpad, st->ln_g[i], st->ln_b[i], m.bias, m.colsum, m.bias_ln, stream)) {
-                    pd_set_error("LayerNorm fold launch failed");
-                    return 1;
-                }
+            // the shape gate of the fused tail that does not depend on the call (320 channels, 8 heads of 40, <= 96 context keys)
+            const bool fused = tail && st_tail_eligible(P, st->C, cfg.num_heads, 128, cfg.context_len);
+            if (on) PD_TRY(fold(st->qkv, st->ln_g[0], st->ln_b[0]));        // norm1 -> to_q/k/v
+            if (on || fused) PD_TRY(fold(st->q2, st->ln_g[1], st->ln_b[1])); // norm2 -> attn2.to_q
+            if (!fused) continue;   // (norm3 stays a kernel in front of the GEGLU tile of gemm.hip)
+            PD_TRY(fold(st->ff1, st->ln_g[2], st->ln_b[2]));                 // norm3 -> ff.net.0 (fused tail only)
+            if (!st->tail_w) {
+                st->tail_w = dmalloc(st_tail_weight_bytes());
+                st->tail_vec = reinterpret_cast<float*>(dmalloc(st_tail_vec_floats() * sizeof(float)));
+                if (!st->tail_w || !st->tail_vec) { pd_set_error("allocation of the fused transformer-tail weights failed"); return 1; }
+            }
+            if (launch_st_tail_pack(st->out1.w, st->q2.w_ln, st->out2.w, st->ff1.w_ln, st->ff2.w, st->proj_out.m.w, st->out1.Kpad, st->ff2.Kpad,
+                                    st->tail_w, stream) ||
+                launch_st_tail_vec(st->out1.bias, st->q2.bias_ln, st->out2.bias, st->ff1.bias_ln, st->ff2.bias, st->proj_out.m.bias, st->tail_vec,
+                                   stream)) {
+                pd_set_error("fused transformer-tail weight packing failed");
+                return 1;
             }
         }
     }
@@ -943,6 +965,24 @@ int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& k
     Act att = new_act(B, H, W, C, T);
     const size_t eb = dt_size(T);
     PD_TRY(attention(qk.p, 2 * C, reinterpret_cast<char*>(qk.p) + (size_t)C * eb, 2 * C, vt.p, npad, att.p, C, B, N, N, C));
+    if (st_tail_on(s, N) && s.tail_w && kv.P) {
+        // everything after the self-attention product in one kernel (st_tail.hip): no h1 / q2 / h2 / norm3 / GEGLU / h3 round trips
+        if (!arena.dry) {
+            PD_TRY(check_arena());
+            ++launches;
+            ProfRec rec{};
+            if (profiling) {
+                prof_begin(rec, 4, st_tail_flops((long long)B * N, cfg.context_len));
+                rec.M = B * N; rec.N = C; rec.K = C; rec.taps = 0;
+            }
+            const int r = launch_st_tail(att.p, h.p, x.p, out.p, s.tail_w, s.tail_vec, kv.P, (long long)B * N, N, cfg.context_len, S,
+                                         (float)(1.0 / std::sqrt((double)(C / cfg.num_heads))), P, stream);
+            if (profiling) prof_end(rec);
+            if (r) { pd_set_error("fused transformer-tail launch failed: %s", hipGetErrorString(hipGetLastError())); return 1; }
+        }
+        arena.release(mk);
+        return 0;
+    }
     Act h1 = new_act(B, H, W, C, S);
     PD_TRY(gemm(s.out1, att, h1, 1, 0, 0, 1.f, &h, nullptr, 0, false, nullptr, 0, 0, 0, nullptr, false, nullptr, fuse ? &st1 : nullptr));
     // cross-attention against the hoisted context K / V^T

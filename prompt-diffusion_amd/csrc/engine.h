@@ -79,6 +79,9 @@ struct STW {
     ConvW proj_in, proj_out;
     WMat qkv, out1, q2, kv2, out2, ff1, ff2;
     int kv_slot = -1;  // index into the per-net table of hoisted context K / V^T
+    // fused tail (st_tail.hip): the block's matrices after self-attention in MFMA-fragment order + its fp32 vectors
+    void* tail_w = nullptr;
+    float* tail_vec = nullptr;
 };
 
 struct EncBlock {
@@ -205,7 +208,7 @@ struct Arena {
     void release(size_t m) { top = m; }
 };
 
-struct KVSlot { void* K = nullptr; void* VT = nullptr; };
+struct KVSlot { void* K = nullptr; void* VT = nullptr; void* P = nullptr; };   // P: K / V^T in st_tail.hip's fragment order (fused blocks)
 
 struct Session {
     bool active = false;
@@ -360,6 +363,8 @@ struct pd_engine {
     int fold_layernorms();     // (re)builds the folded weights of every transformer block after a weight change
     bool ln_dirty = true;
     int opt_ln_fuse = -1;      // -1: on in the 2-byte modes, off in the fp32-storage modes; 0 / 1: forced
+    bool opt_st_fuse = true;   // 320-channel SpatialTransformer blocks: one kernel for everything after self-attention (2-byte modes)
+    bool st_tail_on(const STW& s, int rows_per_sample) const;
     int gn_stats(const Act& x, int& nchunk);
     int conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, const float* b, float eps, bool silu, const Act* R,
                 const float* rowvec, int rowvec_stride);

@@ -3,6 +3,7 @@
 // Not used by the sampling path.
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/pdengine_ops.h"
@@ -201,6 +202,62 @@ int pd_op_attention(pd_engine* e, const float* q, const float* k, const float* v
     HIP_OK(hipStreamSynchronize(e->stream));
     HIP_OK(hipMemcpy(o, fo.p, (size_t)B * Nq * C * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// One whole SpatialTransformer block of the engine's own networks (GroupNorm eps 1e-6, proj_in, BasicTransformerBlock, proj_out, + x;
+// attention.py:321-340 and :271-275) with the weights loaded under `prefix` (e.g. "model.diffusion_model.input_blocks.1.1.") on
+// x [B, C, H, W] and context [B, context_len, context_dim], through exactly the code path a sampling step takes -- including the fused
+// tail kernel (st_tail.hip) where it is eligible.
+int pd_op_spatial_transformer(pd_engine* e, const char* prefix, const float* x, const float* ctx, int B, int H, int W, float* y) {
+    if (!e || !prefix || !x || !ctx || !y) { pd_set_error("null argument"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    const std::string pre(prefix);
+    auto it = e->index.find(pre + "norm.weight");
+    if (it == e->index.end()) { pd_set_error("no SpatialTransformer under '%s'", prefix); return 1; }
+    const float* gn_g = e->params[it->second].vdst;
+    STW* st = nullptr;
+    for (NetW* net : {&e->unet, &e->cnet})
+        for (STW* s : net->st_list)
+            if (s->gn_g == gn_g) st = s;
+    if (!st) { pd_set_error("no SpatialTransformer under '%s'", prefix); return 1; }
+    for (const Param& p : e->params)
+        if (!p.loaded && p.name.compare(0, pre.size(), pre) == 0) { pd_set_error("weights not loaded: '%s'", p.name.c_str()); return 1; }
+    e->ln_dirty = true;
+    PD_TRY(e->fold_layernorms());
+    const int C = st->C, L = e->cfg.context_len, D = e->cfg.context_dim, Dp = round_up(D, 8), lpad = round_up(L, 8), N = H * W;
+    const size_t eb = dt_size(e->T);
+    // a private workspace for this call (op hooks run outside a session)
+    const size_t ws = (size_t)64 << 20, act = (size_t)B * N * C * 4;
+    DevBuf work(ws + 48 * act), cin((size_t)B * L * D * 4), cdev((size_t)B * L * Dp * eb), kbuf((size_t)B * L * C * eb), vtbuf((size_t)B * C * lpad * eb),
+        kvp(st_tail_kv_bytes(B)), xin((size_t)B * N * C * dt_size(e->S));
+    if (!work.p || !cin.p || !cdev.p || !kbuf.p || !vtbuf.p || !kvp.p || !xin.p) { pd_set_error("allocation failed"); return 1; }
+    const Arena saved = e->arena;
+    e->arena = Arena{};
+    e->arena.base = reinterpret_cast<char*>(work.p);
+    e->arena.cap = ws + 48 * act;
+    int rc = 0;
+    do {
+        if ((rc = to_dev_nhwc(e, x, xin.p, e->S, B, C, H, W, C))) break;
+        if (hipMemcpy(cin.p, ctx, (size_t)B * L * D * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = 1; break; }
+        if ((rc = launch_cast_rows(reinterpret_cast<const float*>(cin.p), cdev.p, e->T, (long long)B * L, D, Dp, e->stream))) break;
+        Act c, k;
+        c.p = cdev.p; c.B = B; c.H = L; c.W = 1; c.C = Dp; c.dt = e->T;
+        k.p = kbuf.p; k.B = B; k.H = L; k.W = 1; k.C = C; k.dt = e->T;
+        if ((rc = e->gemm(st->kv2, c, k, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vtbuf.p, C, lpad))) break;
+        KVSlot kv;
+        kv.K = kbuf.p; kv.VT = vtbuf.p;
+        if (e->st_tail_on(*st, N) && st->tail_w) {
+            if ((rc = launch_st_tail_kv_pack(kbuf.p, vtbuf.p, kvp.p, B, L, lpad, e->stream))) break;
+            kv.P = kvp.p;
+        }
+        Act a, o;
+        a.p = xin.p; a.B = B; a.H = H; a.W = W; a.C = C; a.dt = e->S;
+        if ((rc = e->transformer(*st, a, o, kv))) break;
+        rc = from_dev_nhwc(e, o.p, e->S, y, B, C, H, W, C);
+    } while (0);
+    (void)hipStreamSynchronize(e->stream);
+    e->arena = saved;
+    return rc;
 }
 
 }  // extern "C"

@@ -230,6 +230,20 @@ int conv_patch_tiles(const GemmParams& p, int prec);  // 0: shape not eligible f
 int launch_conv_patch(const GemmParams& p, int prec, hipStream_t s);
 int launch_conv_patch2(const GemmParams& p, int prec, hipStream_t s);   // conv_patch2.hip: compute / loader wave specialisation (2-byte types)
 int launch_attention(const AttnParams& p, int prec, hipStream_t s);
+// st_tail.hip: everything after the self-attention product of a 320-channel SpatialTransformer block in one kernel (attn1.to_out +
+// residual, norm2, attn2 against the hoisted context K / V, norm3, GEGLU feed-forward, proj_out + the block residual)
+bool st_tail_eligible(int prec, int C, int heads, int rows_per_sample, int Nk);
+size_t st_tail_weight_bytes();
+size_t st_tail_vec_floats();
+size_t st_tail_kv_bytes(int B);
+double st_tail_flops(long long M, int Nk);
+int launch_st_tail_pack(const void* wo1, const void* wq_ln, const void* wo2, const void* w1_ln, const void* w2, const void* wp, int ld_c, int ld_w2,
+                        void* dst, hipStream_t s);
+int launch_st_tail_vec(const float* bo1, const float* bq_ln, const float* bo2, const float* b1_ln, const float* b2, const float* bp, float* dst,
+                       hipStream_t s);
+int launch_st_tail_kv_pack(const void* K, const void* VT, void* dst, int B, int Nk, int lpad, hipStream_t s);
+int launch_st_tail(const void* att, const void* h, const void* x_in, void* out, const void* wpk, const float* vec, const void* kvp, long long M,
+                   int rows_per_sample, int Nk, int s_dt, float scale, int prec, hipStream_t s);
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
                     const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s);

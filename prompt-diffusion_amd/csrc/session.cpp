@@ -129,6 +129,7 @@ int pd_engine::session_setup(const pd_sample_args& a, const int64_t* t_rows, int
         for (STW* st : net.st_list) {
             kv[st->kv_slot].K = arena.alloc((size_t)Bf * L * st->C * dt_size(T));
             kv[st->kv_slot].VT = arena.alloc((size_t)Bf * st->C * lpad * dt_size(T));
+            kv[st->kv_slot].P = (st_tail_on(*st, 128) && st->tail_w) ? arena.alloc(st_tail_kv_bytes(Bf)) : nullptr;
         }
     }
     s.emb_rows = n_rows + 1;  // last row: scratch for pd_sample_eps_at
@@ -185,6 +186,13 @@ int pd_engine::session_setup(const pd_sample_args& a, const int64_t* t_rows, int
             Act k;
             k.p = kv[st->kv_slot].K; k.B = Bf; k.H = L; k.W = 1; k.C = st->C; k.dt = T;
             PD_TRY(gemm(st->kv2, ctx, k, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, kv[st->kv_slot].VT, st->C, lpad));
+            if (kv[st->kv_slot].P && !arena.dry) {   // the same K / V^T in the fused tail's fragment order
+                ++launches;
+                if (launch_st_tail_kv_pack(k.p, kv[st->kv_slot].VT, kv[st->kv_slot].P, Bf, L, lpad, stream)) {
+                    pd_set_error("context K/V packing for the fused transformer tail failed");
+                    return 1;
+                }
+            }
         }
     }
     // ---- guided_hint = input_hint_block(pair) + input_cond_block(query), cldm/cldm.py:306-308
@@ -726,6 +734,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "attn_legacy")) { e->opt_attn_legacy = value != 0; return 0; }
     if (!strcmp(key, "gn_fuse")) { e->opt_gn_fuse = value != 0; return 0; }
     if (!strcmp(key, "ln_fuse")) { e->opt_ln_fuse = (int)value; e->ln_dirty = true; return 0; }
+    if (!strcmp(key, "st_fuse")) { e->opt_st_fuse = value != 0; e->ln_dirty = true; return 0; }
     if (!strcmp(key, "two_streams")) { e->opt_two_streams = value != 0; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }

@@ -135,6 +135,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_op_groupnorm.argtypes = [C.c_void_p, fp, fp, fp] + [C.c_int] * 4 + [C.c_float, C.c_int, fp]
     lib.pd_op_layernorm.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_int, fp]
     lib.pd_op_attention.argtypes = [C.c_void_p, fp, fp, fp] + [C.c_int] * 4 + [fp]
+    lib.pd_op_spatial_transformer.argtypes = [C.c_void_p, C.c_char_p, fp, fp] + [C.c_int] * 3 + [fp]
     if path is None:
         _lib = lib
     return lib
@@ -147,7 +148,7 @@ EXPORTS = [
     "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_wait_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_encode_ex", "pd_text_weights_missing",
     "pd_profile_read", "pd_profile_dump",
     "pd_sd3_configure", "pd_sd3_weights_missing", "pd_sd3_forward", "pd_sd3_control", "pd_sd3_sample",
-    "pd_op_conv2d", "pd_op_linear", "pd_op_linear_fp8", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention",
+    "pd_op_conv2d", "pd_op_linear", "pd_op_linear_fp8", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention", "pd_op_spatial_transformer",
 ]
 
 
@@ -572,3 +573,11 @@ class Engine:
         o = np.empty_like(q)
         self._check(self.lib.pd_op_attention(self._h, q.ctypes.data, k.ctypes.data, v.ctypes.data, B, Nq, Nk, Cc, o.ctypes.data))
         return o
+
+    def op_spatial_transformer(self, prefix: str, x, context):
+        """SpatialTransformer.forward (attention.py:321-340) of the block loaded under `prefix`, through the sampling code path."""
+        x = np.ascontiguousarray(x, np.float32); ctx = np.ascontiguousarray(context, np.float32)
+        B, Cc, H, W = x.shape
+        y = np.empty_like(x)
+        self._check(self.lib.pd_op_spatial_transformer(self._h, prefix.encode(), x.ctypes.data, ctx.ctypes.data, B, H, W, y.ctypes.data))
+        return y
