@@ -275,7 +275,7 @@ def main():
             peak = {"bf16": PEAK_BF16_TFLOPS, "f16": PEAK_BF16_TFLOPS, "f16x2": PEAK_BF16_TFLOPS / 4, "f32": PEAK_F32_TFLOPS}[args.precision]
             classes = {}
             for name, k in (("igemm_kernel[conv3x3]", 0), ("igemm_kernel[linear/conv1x1]", 1), ("conv3x3_patch_kernel", 3),
-                            ("attn_kernel", 2)):
+                            ("attn_kernel", 2), ("st_tail_kernel", 4)):
                 ms, n, fl = eng.profile_read(k)
                 classes[name] = dict(ms=ms, launches=n, avg_us=1e3 * ms / max(n, 1), tflops=fl / max(ms, 1e-9) / 1e9)
             # HBM view of the short-K linear layers (K <= 1280: the igemm launches that are bandwidth- rather than

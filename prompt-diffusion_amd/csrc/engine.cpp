@@ -555,14 +555,21 @@ int pd_engine::fold_layernorms() {
         for (STW* st : net.st_list) {
             // the shape gate of the fused tail that does not depend on the call (320 channels, 8 heads of 40, <= 96 context keys)
             const bool fused = tail && st_tail_eligible(P, st->C, cfg.num_heads, 128, cfg.context_len);
-            if (on) PD_TRY(fold(st->qkv, st->ln_g[0], st->ln_b[0]));        // norm1 -> to_q/k/v
+            if (on || fused) PD_TRY(fold(st->qkv, st->ln_g[0], st->ln_b[0]));   // norm1 -> to_q/k/v
             if (on || fused) PD_TRY(fold(st->q2, st->ln_g[1], st->ln_b[1])); // norm2 -> attn2.to_q
             if (!fused) continue;   // (norm3 stays a kernel in front of the GEGLU tile of gemm.hip)
             PD_TRY(fold(st->ff1, st->ln_g[2], st->ln_b[2]));                 // norm3 -> ff.net.0 (fused tail only)
             if (!st->tail_w) {
                 st->tail_w = dmalloc(st_tail_weight_bytes());
                 st->tail_vec = reinterpret_cast<float*>(dmalloc(st_tail_vec_floats() * sizeof(float)));
-                if (!st->tail_w || !st->tail_vec) { pd_set_error("allocation of the fused transformer-tail weights failed"); return 1; }
+                st->front_w = dmalloc(st_front_weight_bytes());
+                st->front_vec = reinterpret_cast<float*>(dmalloc(st_front_vec_floats() * sizeof(float)));
+                if (!st->tail_w || !st->tail_vec || !st->front_w || !st->front_vec) { pd_set_error("allocation of the fused transformer weights failed"); return 1; }
+            }
+            if (launch_st_front_pack(st->proj_in.m.w, st->qkv.w_ln, st->proj_in.m.Kpad, st->proj_in.m.bias, st->qkv.bias_ln, st->front_w, st->front_vec,
+                                     stream)) {
+                pd_set_error("fused transformer-front weight packing failed");
+                return 1;
             }
             if (launch_st_tail_pack(st->out1.w, st->q2.w_ln, st->out2.w, st->ff1.w_ln, st->ff2.w, st->proj_out.m.w, st->out1.Kpad, st->ff2.Kpad,
                                     st->tail_w, stream) ||
@@ -937,35 +944,61 @@ int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& k
     const int B = x.B, H = x.H, W = x.W, C = s.C, N = H * W;
     out = new_act(B, H, W, C, S);
     const size_t mk = arena.mark();
+    const bool fused = st_tail_on(s, N) && s.tail_w && s.front_w && kv.P;
+    const int npad = round_up(N, 8);
+    Act h, qk, vt, ln;
+    LnStats st0, st1;
+    const bool fuse = (opt_ln_fuse < 0 ? !f32 : opt_ln_fuse != 0) && s.qkv.w_ln != nullptr;
+    if (fused) {
+        // GroupNorm statistics -> per-(sample, channel) {scale, shift}; the apply, proj_in, norm1 and to_q/k/v are one kernel
+        int nchunk = 1;
+        PD_TRY(gn_stats(x, nchunk));
+        float* coef = reinterpret_cast<float*>(arena.alloc((size_t)B * C * 2 * sizeof(float)));
+        h = new_act(B, H, W, C, S);
+        qk = new_act(B, H, W, 2 * C, T);
+        vt = new_act(B, C, 1, npad, T);
+        if (!arena.dry) {
+            PD_TRY(check_arena());
+            launches += 2;
+            if (launch_gn_coef(gn_partial, s.gn_g, s.gn_b, coef, B, N, C, 32, nchunk, 1e-6f, stream)) {
+                pd_set_error("groupnorm coefficient launch failed");
+                return 1;
+            }
+            ProfRec rec{};
+            if (profiling) {
+                prof_begin(rec, 4, st_front_flops((long long)B * N));
+                rec.M = B * N; rec.N = 4 * C; rec.K = C; rec.taps = 1;
+            }
+            const int r = launch_st_front(x.p, coef, h.p, qk.p, vt.p, s.front_w, s.front_vec, (long long)B * N, N, npad, P, stream);
+            if (profiling) prof_end(rec);
+            if (r) { pd_set_error("fused transformer-front launch failed: %s", hipGetErrorString(hipGetLastError())); return 1; }
+        }
+    } else {
     Act a = new_act(B, H, W, C, T);
     PD_TRY(groupnorm(x, a, s.gn_g, s.gn_b, 1e-6f, false));
-    const bool fuse = (opt_ln_fuse < 0 ? !f32 : opt_ln_fuse != 0) && s.qkv.w_ln != nullptr;
     // LayerNorm statistics travel from the epilogue that writes h / h1 / h2 to the GEMM that consumes norm1/2/3 of it
-    // (fold_layernorms): at most 16 column-range partials per row
-    LnStats st0, st1;
+    // (fold_layernorms): one partial per 80-column wave range of the narrowest tile
     if (fuse) {
-        // one {sum, sum of squares} pair per row and per 80-column wave range of the narrowest tile (160 columns, 2 waves across)
         st0.cap_parts = st1.cap_parts = ((C + 159) / 160) * 2;
         const size_t cap = (size_t)B * N * (size_t)st0.cap_parts * 2 * sizeof(float);
         st0.stats = reinterpret_cast<float*>(arena.alloc(cap));
         st1.stats = reinterpret_cast<float*>(arena.alloc(cap));
     }
-    Act h = new_act(B, H, W, C, S);
+    h = new_act(B, H, W, C, S);
     PD_TRY(gemm(s.proj_in.m, a, h, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0, 0, nullptr, false, nullptr, fuse ? &st0 : nullptr));
     // self-attention: fused QKV projection; V stored transposed for the attention kernel
-    Act ln;
     if (!fuse) {
         ln = new_act(B, H, W, C, T);
         PD_TRY(layernorm(h, ln, s.ln_g[0], s.ln_b[0]));
     }
-    Act qk = new_act(B, H, W, 2 * C, T);
-    const int npad = round_up(N, 8);
-    Act vt = new_act(B, C, 1, npad, T);
+    qk = new_act(B, H, W, 2 * C, T);
+    vt = new_act(B, C, 1, npad, T);
     PD_TRY(gemm(s.qkv, fuse ? h : ln, qk, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * C, npad, 0, nullptr, false, fuse ? &st0 : nullptr));
+    }
     Act att = new_act(B, H, W, C, T);
     const size_t eb = dt_size(T);
     PD_TRY(attention(qk.p, 2 * C, reinterpret_cast<char*>(qk.p) + (size_t)C * eb, 2 * C, vt.p, npad, att.p, C, B, N, N, C));
-    if (st_tail_on(s, N) && s.tail_w && kv.P) {
+    if (fused) {
         // everything after the self-attention product in one kernel (st_tail.hip): no h1 / q2 / h2 / norm3 / GEGLU / h3 round trips
         if (!arena.dry) {
             PD_TRY(check_arena());

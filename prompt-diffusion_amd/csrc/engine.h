@@ -82,6 +82,8 @@ struct STW {
     // fused tail (st_tail.hip): the block's matrices after self-attention in MFMA-fragment order + its fp32 vectors
     void* tail_w = nullptr;
     float* tail_vec = nullptr;
+    void* front_w = nullptr;    // proj_in + to_q/k/v (norm1 folded) in the same order, for the fused front kernel
+    float* front_vec = nullptr;
 };
 
 struct EncBlock {

@@ -237,6 +237,13 @@ size_t st_tail_weight_bytes();
 size_t st_tail_vec_floats();
 size_t st_tail_kv_bytes(int B);
 double st_tail_flops(long long M, int Nk);
+// ... and its front: GroupNorm apply + proj_in + norm1 + to_q / to_k / to_v (h, q | k and V^T out)
+size_t st_front_weight_bytes();
+size_t st_front_vec_floats();
+double st_front_flops(long long M);
+int launch_st_front_pack(const void* wpi, const void* wqkv_ln, int ld, const float* bpi, const float* bqkv_ln, void* wdst, float* vdst, hipStream_t s);
+int launch_st_front(const void* x, const float* coef, void* h, void* qk, void* vt, const void* wpk, const float* vec, long long M, int rows_per_sample,
+                    int vt_ld, int prec, hipStream_t s);
 int launch_st_tail_pack(const void* wo1, const void* wq_ln, const void* wo2, const void* w1_ln, const void* w2, const void* wp, int ld_c, int ld_w2,
                         void* dst, hipStream_t s);
 int launch_st_tail_vec(const float* bo1, const float* bq_ln, const float* bo2, const float* b1_ln, const float* b2, const float* bp, float* dst,

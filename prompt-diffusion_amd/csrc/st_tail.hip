@@ -32,21 +32,22 @@ constexpr int TNT = 10;          // 32-channel tiles
 constexpr int TKS = 20;          // k16 steps over TC
 constexpr int THD = 8, TDH = 40; // heads x head dim
 constexpr int THID = 1280;       // feed-forward hidden units (x and gate each)
-constexpr int TCHUNK = 64;       // hidden units per feed-forward chunk
+constexpr int TCHUNK = 32;       // hidden units per feed-forward chunk
 constexpr int TNCHUNK = THID / TCHUNK;
 constexpr int SF = 20;           // fragments per ring step
 constexpr int NS = 6;            // ring slots
 constexpr int PD = 5;            // steps requested ahead
 constexpr int STEP_BYTES = SF * 1024;
 constexpr int RING_BYTES = NS * STEP_BYTES;
-// weight stream (fragments): A attn1.to_out | B 4 x [q 60 | attn2.to_out 60] | C 20 x [ff.net.0 80 | ff.net.2 40] | D proj_out
-constexpr int WF_A = TNT * TKS, WF_PAIR = 120, WF_B = 4 * WF_PAIR, WF_CHUNK = 120, WF_C = TNCHUNK * WF_CHUNK, WF_D = TNT * TKS;
+// weight stream (fragments): A attn1.to_out | B 4 x [q 60 | attn2.to_out 60] | C feed-forward, 40 chunks of [ff.net.0 40 | ff.net.2 20] in
+// software-pipelined order: W1(0), {W1(c+1), W2(c)} for c = 0..38, W2(39) | D proj_out
+constexpr int WF_A = TNT * TKS, WF_PAIR = 120, WF_B = 4 * WF_PAIR, WF_CHUNK = 60, WF_C = TNCHUNK * WF_CHUNK, WF_D = TNT * TKS;
 constexpr int WF_TOTAL = WF_A + WF_B + WF_C + WF_D;   // 3280
 constexpr int KV_PAIR = 60;      // fragments per head pair: [K h0 9][V h0 12][K h1 9][V h1 12][pad 18]
-constexpr int STEPS_A = 10, STEPS_PAIR = 9, STEPS_CHUNK = 6, STEPS_D = 10;
+constexpr int STEPS_A = 10, STEPS_PAIR = 9, STEPS_CHUNK = 3, STEPS_D = 10;
 constexpr int STEPS_TOTAL = STEPS_A + 4 * STEPS_PAIR + TNCHUNK * STEPS_CHUNK + STEPS_D;   // 176
 // fp32 vectors in LDS behind the ring
-constexpr int V_BO1 = 0, V_BQ = 320, V_BO2 = V_BQ + 384, V_B1 = V_BO2 + 320, V_B2 = V_B1 + TNCHUNK * 4 * 32, V_BP = V_B2 + 320, V_TOTAL = V_BP + 320;
+constexpr int V_BO1 = 0, V_BQ = 320, V_BO2 = V_BQ + 384, V_B1 = V_BO2 + 320, V_B2 = V_B1 + TNCHUNK * 2 * 32, V_BP = V_B2 + 320, V_TOTAL = V_BP + 320;
 
 __host__ __device__ constexpr int sigma(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 __host__ __device__ constexpr int kmap0(int ks, int hk) { return 32 * (ks >> 1) + 16 * hk + 8 * (ks & 1); }
@@ -93,7 +94,12 @@ struct StTailArgs {
     float scale_log2e;    // dh^-0.5 * log2(e)
 };
 
+// front kernel (GroupNorm apply + proj_in + norm1 + to_q/k/v): [proj_in 200 | qkv 600] fragments, a linear stream of 40 steps
+constexpr int FR_STEPS = 40, FR_WF = FR_STEPS * SF;
+constexpr int FV_BPI = 0, FV_BQKV = 320, FV_COEF = FV_BQKV + 960, FV_TOTAL = FV_COEF + 640;
+
 // the ring: one wave-uniform cursor; step st lives in slot st % NS
+template <int KIND>
 struct Pipe {
     const char* wsrc;   // weight stream (wave-uniform)
     const char* kvsrc;  // this sample's K / V fragments (wave-uniform)
@@ -107,6 +113,7 @@ struct Pipe {
         if constexpr (I == 0) return w0; else if constexpr (I == 1) return w1; else if constexpr (I == 2) return w2; else return w3;
     }
     __device__ __forceinline__ const char* step_src(int s) const {
+        if constexpr (KIND == 1) return wsrc + (size_t)(s < FR_STEPS ? s : FR_STEPS - 1) * STEP_BYTES;
         if (s >= STEPS_TOTAL) s = STEPS_TOTAL - 1;   // past the end: keep the request count per step uniform (harmless re-reads)
         if (s < STEPS_A) return wsrc + (size_t)s * STEP_BYTES;
         if (s < STEPS_A + 4 * STEPS_PAIR) {
@@ -134,7 +141,9 @@ struct Pipe {
 // One ring step: 20 fragments, fragment f handed to op(f, fragment) in order while fragment f + 4 is being read; the step's
 // barrier sits after fragment 9: every wave's own requests for step st + 1 have landed (all but the 15 youngest of its
 // LDS-DMAs are complete), all waves are past step st - 1, so its slot takes the requests for step st + 5.
-template <class F> __device__ __forceinline__ void run_step(Pipe& pp, F&& op) {
+// NV > 0: the step's ops carry independent vector work (x * gelu(gate) of the previous feed-forward chunk): up to NV of those
+// instructions are placed behind every MFMA, where they issue under its 32 cycles
+template <int NV = 0, class PIPE, class F> __device__ __forceinline__ void run_step(PIPE& pp, F&& op) {
     static_for<SF>([&](auto I) __attribute__((always_inline)) {
         constexpr int f = decltype(I)::value;
         uint4& w = pp.template reg<f % 4>();
@@ -142,6 +151,7 @@ template <class F> __device__ __forceinline__ void run_step(Pipe& pp, F&& op) {
         if constexpr (f + 4 < SF) w = ldsr(pp.cur + (f + 4) * 1024); else w = ldsr(pp.nxt + (f + 4 - SF) * 1024);
         if (used) __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (NV > 0) __builtin_amdgcn_sched_group_barrier(0x2, NV, 0);
         if constexpr (f == 9) {
             asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
     const int hh = lane >> 5;
     const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
 
-    Pipe pp;
+    Pipe<0> pp;
     pp.wsrc = a.wpk;
     pp.kvsrc = a.kvp + (size_t)((blockIdx.x * 128) / a.rows_per_sample) * (4 * KV_PAIR * 1024);
     pp.st = 0;
@@ -359,37 +369,54 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
 #pragma unroll
     for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_BO2 + 32 * t + 16 * hh);
 
-    // ---- 6-8. GEGLU feed-forward in chunks of 64 hidden units: [x0 | gate0 | x1 | gate1] tiles, then 4 k16 steps into h3
+    // ---- 6-8. GEGLU feed-forward in chunks of 32 hidden units, software-pipelined: while the matrix pipe runs ff.net.0 of chunk
+    // c + 1 ([x | gate] tiles, 40 MFMAs) the vector pipe does x * gelu(gate) of chunk c, 2 values per 5 MFMAs; then ff.net.2 of
+    // chunk c (2 k16 steps into each of the 10 output tiles)
     ln_frags<P>(acc, yf);   // norm3
 #pragma unroll
     for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_B2 + 32 * t + 16 * hh);
-    for (int cc = 0; cc < TNCHUNK; ++cc) {
-        f32x16 a1[4];
-        static_for<4>([&](auto TI) __attribute__((always_inline)) {
+    f32x16 a1[2];
+    static_for<2>([&](auto TI) __attribute__((always_inline)) {
+        constexpr int ti = decltype(TI)::value;
+        a1[ti] = lds_vec16(V_B1 + ti * 32 + 16 * hh);
+        run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
+            mfma32<P>(w, yf[decltype(I)::value], a1[ti]);
+            return true;
+        });
+    });
+    for (int cc = 0; cc < TNCHUNK - 1; ++cc) {
+        f32x16 a1n[2], g;
+        static_for<2>([&](auto TI) __attribute__((always_inline)) {
             constexpr int ti = decltype(TI)::value;
-            a1[ti] = lds_vec16(V_B1 + (cc * 4 + ti) * 32 + 16 * hh);
-            run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
-                mfma32<P>(w, yf[decltype(I)::value], a1[ti]);
+            a1n[ti] = lds_vec16(V_B1 + ((cc + 1) * 2 + ti) * 32 + 16 * hh);
+            run_step<0>(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
+                constexpr int o = ti * SF + decltype(I)::value;
+                mfma32<P>(w, yf[decltype(I)::value], a1n[ti]);
+                if constexpr (o % 5 == 0 || o % 5 == 2) {
+                    constexpr int gi = (o / 5) * 2 + (o % 5 == 2 ? 1 : 0);
+                    g[gi] = a1[0][gi] * gelu_fast(a1[1][gi]);
+                }
                 return true;
             });
         });
-        uint4 gf[4];
+        const uint4 gf0 = acc_frag<P, 0>(g), gf1 = acc_frag<P, 1>(g);
+        run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
+            constexpr int o = decltype(I)::value;
+            mfma32<P>(w, (o & 1) ? gf1 : gf0, acc[o / 2]);
+            return true;
+        });
+        a1[0] = a1n[0];
+        a1[1] = a1n[1];
+    }
+    {
+        f32x16 g;
 #pragma unroll
-        for (int xt = 0; xt < 2; ++xt) {
-            f32x16 g;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = a1[2 * xt][r] * gelu_fast(a1[2 * xt + 1][r]);
-            gf[2 * xt] = acc_frag<P, 0>(g);
-            gf[2 * xt + 1] = acc_frag<P, 1>(g);
-        }
-        static_for<2>([&](auto SG) __attribute__((always_inline)) {
-            constexpr int sg = decltype(SG)::value;
-            run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
-                constexpr int o = sg * SF + decltype(I)::value;
-                constexpr int tn = o / 4, ksl = o % 4;
-                mfma32<P>(w, gf[ksl], acc[tn]);
-                return true;
-            });
+        for (int r = 0; r < 16; ++r) g[r] = a1[0][r] * gelu_fast(a1[1][r]);
+        const uint4 gf0 = acc_frag<P, 0>(g), gf1 = acc_frag<P, 1>(g);
+        run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
+            constexpr int o = decltype(I)::value;
+            mfma32<P>(w, (o & 1) ? gf1 : gf0, acc[o / 2]);
+            return true;
         });
     }
 
@@ -411,6 +438,143 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (clamped) requests must have landed before the LDS is released
 #pragma unroll
     for (int t = 0; t < TNT; ++t) store_row16<P, SF32>(a.out, (size_t)row * TC + 32 * t + 16 * hh, acc[t]);
+}
+
+
+// ------------------------------------------------------------------------------------------------ front of the block
+// h = proj_in(GroupNorm(x)) (attention.py:331-333; GroupNorm statistics arrive as per-(sample, channel) {scale, shift}), then
+// [q | k | v] = norm1(h) . Wqkv^T (attention.py:271: attn1 of norm1(x); gamma / beta folded into the weights / a bias).
+// Outputs: h [M][320] (the residual the tail kernel adds), q | k [M][640] row-major, V^T [B][320][vt_ld] for the attention kernel.
+struct StFrontArgs {
+    const void* x;        // [M][320] stream type
+    const float* coef;    // [B][320][2] GroupNorm {scale, shift}
+    void* h;              // [M][320] stream type
+    void* qk;             // [M][640] compute type
+    void* vt;             // [B][320][vt_ld] compute type
+    const char* wpk;      // FR_WF fragments
+    const float* vec;     // b_proj_in[320] | b_qkv[960]
+    int rows_per_sample, vt_ld;
+};
+
+template <int P>
+__global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5;
+    const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int sample = (blockIdx.x * 128) / a.rows_per_sample;
+    const int tok = row - sample * a.rows_per_sample;
+
+    Pipe<1> pp;
+    pp.wsrc = a.wpk;
+    pp.kvsrc = a.wpk;
+    pp.st = 0;
+    pp.lane16 = lane * 16;
+    pp.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    pp.wave = sgpr(wave);
+    for (int s = 0; s < PD; ++s) pp.issue(s);
+    {
+        f32x4* dst = reinterpret_cast<f32x4*>(smem + RING_BYTES);
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.vec);
+        for (int i = tid; i < FV_COEF / 4; i += 256) dst[i] = src[i];
+        const f32x4* cs = reinterpret_cast<const f32x4*>(a.coef + (size_t)sample * TC * 2);
+        for (int i = tid; i < 640 / 4; i += 256) dst[FV_COEF / 4 + i] = cs[i];
+    }
+    uint4 xr[TKS];
+    {
+        const uint16_t* xp = reinterpret_cast<const uint16_t*>(a.x) + (size_t)row * TC;
+#pragma unroll
+        for (int ks = 0; ks < TKS; ++ks) xr[ks] = *reinterpret_cast<const uint4*>(xp + kmap0(ks, hh));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // GroupNorm apply while the rows become B fragments: y = x * scale[c] + shift[c], rounded to the compute type like the
+    // per-layer path's GroupNorm output
+    uint4 yf[TKS];
+#pragma unroll
+    for (int ks = 0; ks < TKS; ++ks) {
+        float f[8];
+        unpack8<P>(xr[ks], f);
+        const f32x4* cf = reinterpret_cast<const f32x4*>(smem + RING_BYTES) + (FV_COEF + 2 * kmap0(ks, hh)) / 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 c = cf[j];   // {scale, shift} of two channels
+            f[2 * j] = fmaf(f[2 * j], c[0], c[1]);
+            f[2 * j + 1] = fmaf(f[2 * j + 1], c[2], c[3]);
+        }
+        yf[ks] = pack8<P>(f);
+    }
+    f32x16 acc[TNT];
+#pragma unroll
+    for (int t = 0; t < TNT; ++t) acc[t] = lds_vec16(FV_BPI + 32 * t + 16 * hh);
+    pp.cur = pp.lane16;
+    pp.nxt = STEP_BYTES + pp.lane16;
+    pp.w0 = ldsr(pp.cur); pp.w1 = ldsr(pp.cur + 1024); pp.w2 = ldsr(pp.cur + 2048); pp.w3 = ldsr(pp.cur + 3072);
+    static_for<TNT>([&](auto TN) __attribute__((always_inline)) {
+        constexpr int tn = decltype(TN)::value;
+        run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
+            mfma32<P>(w, yf[decltype(I)::value], acc[tn]);
+            return true;
+        });
+    });
+    // the residual stream is stored in the (2-byte) stream type; norm1 sees the same rounded values the per-layer path reads back
+#pragma unroll
+    for (int t = 0; t < TNT; ++t) {
+        const uint4 lo = acc_frag<P, 0>(acc[t]), hi = acc_frag<P, 1>(acc[t]);
+        uint4* hp = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.h) + (size_t)row * TC + 32 * t + 16 * hh);
+        hp[0] = lo;
+        hp[1] = hi;
+        float f[16];
+        unpack8<P>(lo, f);
+        unpack8<P>(hi, f + 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = f[r];
+    }
+    ln_frags<P>(acc, yf);   // norm1
+    // q | k | v: 30 output tiles, one ring step each
+    uint16_t* qkrow = reinterpret_cast<uint16_t*>(a.qk) + (size_t)row * (2 * TC) + 16 * hh;
+    uint16_t* vtp = reinterpret_cast<uint16_t*>(a.vt) + ((size_t)sample * TC + 16 * hh) * a.vt_ld + tok;
+    for (int tg = 0; tg < 30; tg += 2) {   // two tiles per trip keeps the loop body at 40 MFMAs
+        f32x16 o0 = lds_vec16(FV_BQKV + 32 * tg + 16 * hh), o1 = lds_vec16(FV_BQKV + 32 * (tg + 1) + 16 * hh);
+        run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
+            mfma32<P>(w, yf[decltype(I)::value], o0);
+            return true;
+        });
+        run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
+            mfma32<P>(w, yf[decltype(I)::value], o1);
+            return true;
+        });
+        if (tg < 20) {
+            uint4* d0 = reinterpret_cast<uint4*>(qkrow + 32 * tg);
+            d0[0] = acc_frag<P, 0>(o0); d0[1] = acc_frag<P, 1>(o0);
+            d0[4] = acc_frag<P, 0>(o1); d0[5] = acc_frag<P, 1>(o1);
+        } else {
+            // V^T[sample][channel][token]: lanes 0..31 of a half wave are 32 consecutive tokens of one channel (64-byte runs)
+            uint16_t* v0 = vtp + (size_t)(32 * (tg - 20)) * a.vt_ld;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v0[(size_t)r * a.vt_ld] = cvt16<P>(o0[r]);
+                v0[(size_t)(32 + r) * a.vt_ld] = cvt16<P>(o1[r]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+struct StFrontPackArgs { const uint16_t *wpi, *wqkv; int ld; uint16_t* dst; };
+__global__ __launch_bounds__(256) void st_front_pack_kernel(StFrontPackArgs a) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int F = gid >> 6, lane = gid & 63;
+    if (F >= FR_WF) return;
+    const int i = lane & 31, hk = lane >> 5;
+    const int tn = F / TKS, ks = F % TKS;   // tiles 0..9: proj_in, 10..39: the fused to_q | to_k | to_v rows
+    const uint16_t* src = tn < TNT ? a.wpi + (size_t)(32 * tn + sigma(i)) * a.ld + kmap0(ks, hk)
+                                   : a.wqkv + (size_t)(32 * (tn - TNT) + sigma(i)) * a.ld + kmap0(ks, hk);
+    reinterpret_cast<uint4*>(a.dst)[gid] = *reinterpret_cast<const uint4*>(src);
+}
+__global__ __launch_bounds__(256) void st_front_vec_kernel(const float* bpi, const float* bqkv, float* dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < FV_BQKV) dst[i] = bpi[i];
+    else if (i < FV_COEF) dst[i] = bqkv[i - FV_BQKV];
 }
 
 // ------------------------------------------------------------------------------------------------ packing
@@ -444,14 +608,20 @@ __global__ __launch_bounds__(256) void st_tail_pack_kernel(StPackArgs a) {
             if (d0 < TDH) src = a.wo2 + (size_t)(32 * tn + sigma(i)) * a.ld_c + (2 * pr + hl) * TDH + d0;
         }
     } else if (F < WF_A + WF_B + WF_C) {
-        const int cc = (F - WF_A - WF_B) / WF_CHUNK, r = (F - WF_A - WF_B) % WF_CHUNK;
-        if (r < 80) {
-            const int ti = r / TKS, ks = r % TKS;
-            const int u = TCHUNK * cc + 32 * (ti >> 1) + sigma(i);
-            src = a.w1 + (size_t)geglu_row(u, ti & 1) * a.ld_c + kmap0(ks, hk);
+        const int r = F - WF_A - WF_B;
+        int cc, idx;      // chunk and index inside its ff.net.0 (idx < 40) or ff.net.2 (idx >= 40) fragments
+        if (r < 40) { cc = 0; idx = r; }
+        else if (r >= WF_C - 20) { cc = TNCHUNK - 1; idx = 40 + r - (WF_C - 20); }
+        else {
+            const int b = (r - 40) / 60, q = (r - 40) % 60;
+            if (q < 40) { cc = b + 1; idx = q; } else { cc = b; idx = q; }
+        }
+        if (idx < 40) {
+            const int gate = idx / TKS, ks = idx % TKS;
+            src = a.w1 + (size_t)geglu_row(TCHUNK * cc + sigma(i), gate) * a.ld_c + kmap0(ks, hk);
         } else {
-            const int o = r - 80, tn = o / 4, ksl = o % 4;
-            src = a.w2 + (size_t)(32 * tn + sigma(i)) * a.ld_w2 + TCHUNK * cc + 32 * (ksl >> 1) + 16 * hk + 8 * (ksl & 1);
+            const int o = idx - 40, tn = o / 2, ksl = o % 2;
+            src = a.w2 + (size_t)(32 * tn + sigma(i)) * a.ld_w2 + TCHUNK * cc + 16 * hk + 8 * ksl;
         }
     } else {
         const int r = F - WF_A - WF_B - WF_C, tn = r / TKS, ks = r % TKS;
@@ -474,8 +644,8 @@ __global__ __launch_bounds__(256) void st_tail_vec_kernel(StVecArgs a) {
         v = d < TDH ? a.bq[head * TDH + d] : 0.f;
     } else if (i < V_B1) v = a.bo2[i - V_BO2];
     else if (i < V_B2) {
-        const int k = i - V_B1, cc = k / 128, ti = (k % 128) / 32, c = k % 32;
-        v = a.b1[geglu_row(TCHUNK * cc + 32 * (ti >> 1) + c, ti & 1)];
+        const int k = i - V_B1, cc = k / 64, gate = (k % 64) / 32, c = k % 32;
+        v = a.b1[geglu_row(TCHUNK * cc + c, gate)];
     } else if (i < V_BP) v = a.b2[i - V_B2];
     else v = a.bp[i - V_BP];
     a.dst[i] = v;
@@ -514,6 +684,32 @@ __global__ __launch_bounds__(256) void st_tail_kv_pack_kernel(const uint16_t* K,
 }
 
 }  // namespace
+
+
+size_t st_front_weight_bytes() { return (size_t)FR_WF * 1024; }
+size_t st_front_vec_floats() { return FV_COEF; }
+double st_front_flops(long long M) { return 2.0 * (double)M * TC * (4.0 * TC); }   // proj_in + to_q / to_k / to_v
+int launch_st_front_pack(const void* wpi, const void* wqkv_ln, int ld, const float* bpi, const float* bqkv_ln, void* wdst, float* vdst, hipStream_t s) {
+    StFrontPackArgs a{reinterpret_cast<const uint16_t*>(wpi), reinterpret_cast<const uint16_t*>(wqkv_ln), ld, reinterpret_cast<uint16_t*>(wdst)};
+    hipLaunchKernelGGL(st_front_pack_kernel, dim3(FR_WF * 64 / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(st_front_vec_kernel, dim3((FV_COEF + 255) / 256), dim3(256), 0, s, bpi, bqkv_ln, vdst);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int launch_st_front(const void* x, const float* coef, void* h, void* qk, void* vt, const void* wpk, const float* vec, long long M, int rows_per_sample,
+                    int vt_ld, int prec, hipStream_t s) {
+    if (M % 128 || rows_per_sample % 128) return 1;
+    StFrontArgs a{x, coef, h, qk, vt, reinterpret_cast<const char*>(wpk), vec, rows_per_sample, vt_ld};
+    constexpr int SMEM = RING_BYTES + FV_TOTAL * 4;
+    static unsigned long long done[2] = {0, 0};
+    void (*kfn)(StFrontArgs) = nullptr;
+    int slot = 0;
+    if (prec == DT_F16) { kfn = st_front_kernel<DT_F16>; slot = 0; }
+    else if (prec == DT_BF16) { kfn = st_front_kernel<DT_BF16>; slot = 1; }
+    else return 1;
+    if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM, &done[slot])) return 1;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(M / 128)), dim3(256), SMEM, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 
 size_t st_tail_weight_bytes() { return (size_t)WF_TOTAL * 1024; }
 size_t st_tail_vec_floats() { return V_TOTAL; }

@@ -15,7 +15,7 @@ KS = 20            # k16 steps over C
 HEADS = 8
 DH = 40
 HID = 1280
-CHUNK = 64         # hidden units per feed-forward chunk
+CHUNK = 32         # hidden units per feed-forward chunk
 NCHUNK = HID // CHUNK
 
 
@@ -105,19 +105,26 @@ def pack_weights(Wo1, Wq, g2, Wo2, W1, g3, W2, Wp):
                 for ksl in range(3):
                     fr.append(frag_generic(Wo2, lambda i: 32 * tn + sigma(i), lambda hk, j: head_in(hd, ksl, hk, j)))
     W1_f = W1 * g3[None, :]
-    for cc in range(NCHUNK):                               # C: feed-forward, 64 hidden units per chunk
-        for ti in range(4):
-            xt, gate = ti >> 1, ti & 1
 
-            def orow(i, xt=xt, gate=gate):
-                u = CHUNK * cc + 32 * xt + sigma(i)
+    def w1_frags(cc):                                      # [x tile | gate tile] of chunk cc: 40 fragments
+        out = []
+        for gate in range(2):
+            def orow(i, gate=gate):
+                u = CHUNK * cc + sigma(i)
                 return HID + u if gate else u
             for ks in range(KS):
-                fr.append(frag_generic(W1_f, orow, lambda hk, j: kmap(ks, hk, j)))
-        for tn in range(NT):
-            for ksl in range(4):
-                fr.append(frag_generic(W2, lambda i: 32 * tn + sigma(i),
-                                       lambda hk, j: CHUNK * cc + 32 * (ksl >> 1) + 16 * hk + 8 * (ksl & 1) + j))
+                out.append(frag_generic(W1_f, orow, lambda hk, j: kmap(ks, hk, j)))
+        return out
+
+    def w2_frags(cc):                                      # 20 fragments: 2 k16 steps per output tile
+        return [frag_generic(W2, lambda i: 32 * tn + sigma(i), lambda hk, j: CHUNK * cc + 16 * hk + 8 * ksl + j)
+                for tn in range(NT) for ksl in range(2)]
+    # C: feed-forward, 32 hidden units per chunk, software-pipelined: ff.net.0 of chunk c+1 streams in front of ff.net.2 of chunk c
+    fr += w1_frags(0)
+    for cc in range(NCHUNK - 1):
+        fr += w1_frags(cc + 1)
+        fr += w2_frags(cc)
+    fr += w2_frags(NCHUNK - 1)
     for tn in range(NT):                                   # D: proj_out
         for ks in range(KS):
             fr.append(frag_generic(Wp, lambda i: 32 * tn + sigma(i), lambda hk, j: kmap(ks, hk, j)))
@@ -155,7 +162,7 @@ def pack_kv(K2, V2, Nk):
 
 
 def pack_vectors(bo1, Wq, b2n, bo2, b1, W1, b3n, bff2, bp):
-    """fp32 vectors in the order the kernel indexes them: bo1[320] | bq[384 slots] | bo2[320] | b1'[NCHUNK*4*32] | b2[320] | bp[320]."""
+    """fp32 vectors in the order the kernel indexes them: bo1[320] | bq[384 slots] | bo2[320] | b1'[NCHUNK*2*32] | b2[320] | bp[320]."""
     bq_full = Wq @ b2n                                      # beta of norm2 through attn2.to_q
     bq = np.zeros(384)
     for tq in range(12):
@@ -164,13 +171,12 @@ def pack_vectors(bo1, Wq, b2n, bo2, b1, W1, b3n, bff2, bp):
             if s is not None:
                 bq[32 * tq + sigma(i)] = bq_full[s[0] * DH + s[1]]
     b1_full = b1 + W1 @ b3n
-    b1p = np.zeros(NCHUNK * 4 * 32)
+    b1p = np.zeros(NCHUNK * 2 * 32)
     for cc in range(NCHUNK):
-        for ti in range(4):
-            xt, gate = ti >> 1, ti & 1
+        for gate in range(2):
             for c in range(32):
-                u = CHUNK * cc + 32 * xt + c
-                b1p[(cc * 4 + ti) * 32 + c] = b1_full[HID + u if gate else u]
+                u = CHUNK * cc + c
+                b1p[(cc * 2 + gate) * 32 + c] = b1_full[HID + u if gate else u]
     return dict(bo1=bo1, bq=bq, bo2=bo2, b1=b1p, b2=bff2, bp=bp)
 
 
@@ -287,20 +293,28 @@ def run_wave(att, h, x_in, wfr, kvfr, vec, Nk, scale):
     for t in range(NT):
         for l in range(64):
             acc[t, l] += vec["b2"][32 * t + 16 * lane_hh[l]:32 * t + 16 * lane_hh[l] + 16]
-    for cc in range(NCHUNK):
-        a1 = np.zeros((4, 64, 16))
-        for ti in range(4):
+    def gemm1(cc):
+        a1 = np.zeros((2, 64, 16))
+        for ti in range(2):
             for l in range(64):
-                a1[ti, l] = vec["b1"][(cc * 4 + ti) * 32 + 16 * lane_hh[l]:(cc * 4 + ti) * 32 + 16 * lane_hh[l] + 16]
+                a1[ti, l] = vec["b1"][(cc * 2 + ti) * 32 + 16 * lane_hh[l]:(cc * 2 + ti) * 32 + 16 * lane_hh[l] + 16]
             w = take(KS)
             for ks in range(KS):
                 mfma(w[ks], y3[ks], a1[ti])
-        g = np.stack([a1[0] * gelu(a1[1]), a1[2] * gelu(a1[3])])
-        gf = np.concatenate([acc_to_bfrags(g[0]), acc_to_bfrags(g[1])])          # 4 steps
-        w = take(40)
+        return a1
+
+    def gemm2(a1):
+        gf = acc_to_bfrags(a1[0] * gelu(a1[1]))                                  # 2 steps
+        w = take(20)
         for tn in range(NT):
-            for ksl in range(4):
-                mfma(w[tn * 4 + ksl], gf[ksl], acc[tn])
+            for ksl in range(2):
+                mfma(w[tn * 2 + ksl], gf[ksl], acc[tn])
+    a1 = gemm1(0)
+    for cc in range(NCHUNK - 1):
+        a1n = gemm1(cc + 1)
+        gemm2(a1)
+        a1 = a1n
+    gemm2(a1)
     # 9. out = h3 . Wp^T + bp + x_in
     hf = np.concatenate([acc_to_bfrags(acc[t]) for t in range(NT)])
     out = lane_rows_to_acc(x_in + vec["bp"][None, :])

@@ -58,8 +58,7 @@ def test_block_matches_oracle(prec, B, H, Wd):
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 def test_fused_equals_per_layer_path(prec):
-    """same engine, option st_fuse on / off: both within the mode's bound of the oracle and of each other; the fused kernel keeps
-    the residual stream in fp32 registers, so it is the closer of the two"""
+    """same engine, option st_fuse on / off: both within the mode's bound of the oracle and of each other"""
     sd = block_weights()
     x, ctx = inputs(2, 16, 16, seed=9)
     ref = O.spatial_transformer(O.Net(sd, PRE), BLK, x, ctx, heads=8)
@@ -72,10 +71,9 @@ def test_fused_equals_per_layer_path(prec):
     y0 = e.op_spatial_transformer(PRE + BLK, x, ctx)
     n_plain = e.stat("launches") - launches0
     e.close()
-    assert n_fused < n_plain - 6, (n_fused, n_plain)     # 8 launches became 1
+    assert n_fused < n_plain - 6, (n_fused, n_plain)     # 12 launches became 5 (statistics, coefficients, front, attention, tail)
     assert relerr(y1, ref) < TOL[prec] and relerr(y0, ref) < TOL[prec]
     assert relerr(y1, y0) < TOL[prec]
-    assert relerr(y1, ref) <= 1.25 * relerr(y0, ref)
 
 
 def test_stream_f32_and_context_variants():
