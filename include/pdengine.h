@@ -167,6 +167,9 @@ int pd_sample_step(pd_engine* e, int32_t i); /* i = 0..steps-1, asynchronous on 
 #define PD_GET_EPS 2 /* guided noise prediction of the last step */
 int pd_sample_get(pd_engine* e, int32_t what, int32_t mem, float* out);
 int pd_sample_set_latents(pd_engine* e, int32_t mem, const float* latents);
+/* unconditional_guidance_scale of the following steps: DDIMSampler.ddim_sampling's ucg_schedule (cldm/ddim_hacked.py:159-161)
+ * replaces the scale before every p_sample_ddim */
+int pd_sample_set_guidance(pd_engine* e, float scale);
 /* guided eps at an arbitrary timestep for the current latents, no update: lets a host-side
  * scheduler (pipeline :1273 scheduler.step) drive the engine */
 int pd_sample_eps_at(pd_engine* e, int64_t t, const float* scales13);

@@ -45,6 +45,11 @@ def make_ddim_timesteps(num_ddim_timesteps, num_ddpm_timesteps=1000):
     return np.asarray(list(range(0, num_ddpm_timesteps, c))) + 1
 
 
+def make_ddim_timesteps_quad(num_ddim_timesteps, num_ddpm_timesteps=1000):
+    """'quad' branch of util.py:49-50 (+1 like the uniform one, :56)."""
+    return ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int) + 1
+
+
 def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta):
     """util.py:63-74; alphacums is the float32 buffer (ddim_hacked.py:42 passes .cpu())."""
     alphas = alphacums[ddim_timesteps]
@@ -346,7 +351,7 @@ def q_sample(cfg, x_start, t, noise):
 
 def ddim_sampling(sd, cfg, layouts, S, x_T, cond, uncond, cfg_scale, eta=0.0, control_scales=None,
                   noises=None, steps_limit: Optional[int] = None, mask=None, x0=None, q_noise=None, timesteps=None,
-                  temperature=1.0, only_mid_control=False):
+                  temperature=1.0, only_mid_control=False, ucg_schedule=None):
     """DDIMSampler.sample + ddim_sampling, cldm/ddim_hacked.py:55-178 with log_every_t=1.
     mask/x0: the inpainting blend of :154-157, with the q_sample noise of each step supplied (q_noise[i]).
 
@@ -364,11 +369,48 @@ def ddim_sampling(sd, cfg, layouts, S, x_T, cond, uncond, cfg_scale, eta=0.0, co
             img_orig = q_sample(cfg, x0, np.full((img.shape[0],), int(step), np.int64), q_noise[i])
             img = (img_orig * mask + (F32(1.0) - mask) * img).astype(F32)
         nz = None if noises is None else noises[i]
+        if ucg_schedule is not None:        # ddim_hacked.py:159-161
+            assert len(ucg_schedule) == len(time_range)
+            cfg_scale = ucg_schedule[i]
         img, pred_x0, _ = p_sample_ddim(sd, cfg, layouts, sched, img, cond, uncond, index, int(step),
                                         cfg_scale, control_scales, nz, temperature, only_mid_control)
         x_inter.append(img)
         preds.append(pred_x0)
     return img, x_inter, preds
+
+
+def ddim_encode(sd, cfg, layouts, sched, x0, cond, t_enc):
+    """DDIMSampler.encode with unconditional_guidance_scale == 1, cldm/ddim_hacked.py:237-282.  The reference hands the loop
+    index i -- not the DDIM timestep -- to apply_model (:256); restated as it runs."""
+    alphas_next = sched["ddim_alphas"][:t_enc]
+    alphas = sched["ddim_alphas_prev"][:t_enc]
+    x_next = x0
+    one = F32(1.0)
+    for i in range(t_enc):
+        t = np.full((x0.shape[0],), i, dtype=np.int64)
+        noise_pred = apply_model(sd, cfg, layouts, x_next, t, cond["c_crossattn"], cond["example_pair"], cond["query"])
+        xt_weighted = np.sqrt(alphas_next[i] / alphas[i]) * x_next
+        weighted = np.sqrt(alphas_next[i]) * (np.sqrt(one / alphas_next[i] - one) - np.sqrt(one / alphas[i] - one)) * noise_pred
+        x_next = (xt_weighted + weighted).astype(F32)
+    return x_next
+
+
+def stochastic_encode(sched, x0, t, noise):
+    """DDIMSampler.stochastic_encode, cldm/ddim_hacked.py:284-299 (t indexes the DDIM grid)."""
+    t = np.asarray(t, np.int64).reshape(-1)
+    sa = np.sqrt(sched["ddim_alphas"])[t].reshape(-1, 1, 1, 1)
+    sb = sched["ddim_sqrt_one_minus_alphas"][t].reshape(-1, 1, 1, 1)
+    return (sa * x0 + sb * noise).astype(F32)
+
+
+def ddim_decode(sd, cfg, layouts, sched, x_latent, cond, uncond, t_start, cfg_scale):
+    """DDIMSampler.decode, cldm/ddim_hacked.py:301-318 (eta = 0)."""
+    timesteps = sched["ddim_timesteps"][:t_start]
+    x_dec = x_latent
+    for i, step in enumerate(np.flip(timesteps)):
+        index = len(timesteps) - i - 1
+        x_dec, _, _ = p_sample_ddim(sd, cfg, layouts, sched, x_dec, cond, uncond, index, int(step), cfg_scale)
+    return x_dec
 
 
 def make_layouts(cfg, weights_mod):

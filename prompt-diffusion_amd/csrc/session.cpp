@@ -36,8 +36,9 @@ int pd_engine::make_schedule(int steps, float eta, std::vector<int64_t>& ts, std
     if (custom_desc) {
         for (int i = steps - 1; i >= 0; --i) {
             const int64_t t = custom_desc[i];
-            if (t < 0 || t >= T_ || (!ts.empty() && t <= ts.back())) {
-                pd_set_error("custom timesteps must be strictly descending and inside [0, %d)", T_);
+            // (equal neighbours are legal: make_ddim_timesteps('quad') repeats small timesteps, util.py:50)
+            if (t < 0 || t >= T_ || (!ts.empty() && t < ts.back())) {
+                pd_set_error("custom timesteps must be descending and inside [0, %d)", T_);
                 return 1;
             }
             ts.push_back(t);
@@ -626,6 +627,13 @@ int pd_sample_get(pd_engine* e, int32_t what, int32_t mem, float* out) {
     if (launch_nhwc_to_nchw(src, DT_F32, tmp, B, C, h, w, cpad, 1.f, e->stream)) return 1;
     PD_TRY(copy_out(e, tmp, out, n, mem));
     e->arena.release(mk);
+    return 0;
+}
+
+int pd_sample_set_guidance(pd_engine* e, float scale) {
+    if (!e) { pd_set_error("null engine"); return 1; }
+    if (!e->ses.active) { pd_set_error("no active sampling session"); return 1; }
+    e->ses.a.cfg_scale = scale;
     return 0;
 }
 

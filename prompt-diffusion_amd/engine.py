@@ -114,6 +114,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_sample_get.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.pd_sample_set_latents.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.pd_sample_eps_at.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.pd_sample_set_guidance.argtypes = [C.c_void_p, C.c_float]
     lib.pd_sample_end.argtypes = [C.c_void_p]
     lib.pd_make_schedule.argtypes = [C.c_void_p, C.c_int32, C.c_float] + [C.c_void_p] * 5
     lib.pd_synchronize.argtypes = [C.c_void_p]
@@ -144,7 +145,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = [
     "pd_last_error", "pd_abi_version", "pd_engine_create", "pd_engine_destroy", "pd_param_count", "pd_param_info",
     "pd_load_weights", "pd_init_random_weights", "pd_weights_missing", "pd_vae_weights_missing", "pd_vae_decode", "pd_eps", "pd_control_shape", "pd_ddim_sample",
-    "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_eps_at", "pd_sample_end",
+    "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_set_guidance", "pd_sample_eps_at", "pd_sample_end",
     "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_wait_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_encode_ex", "pd_text_weights_missing",
     "pd_profile_read", "pd_profile_dump",
     "pd_sd3_configure", "pd_sd3_weights_missing", "pd_sd3_forward", "pd_sd3_control", "pd_sd3_sample",
@@ -471,6 +472,10 @@ class Engine:
         b = _Buf(latents)
         self._order_after_torch(b.mem)
         self._check(self.lib.pd_sample_set_latents(self._h, b.mem, b.ptr))
+
+    def sample_set_guidance(self, scale: float) -> None:
+        """unconditional_guidance_scale of the following steps (ucg_schedule, cldm/ddim_hacked.py:159-161)."""
+        self._check(self.lib.pd_sample_set_guidance(self._h, float(scale)))
 
     def sample_eps_at(self, t: int, scales: Optional[Sequence[float]] = None):
         sc = None

@@ -237,6 +237,49 @@ def run_mask_case(tag, cfg, W, B, h, w, S, cfg_scale, out):
     print(f"[golden] net_{tag}: {len(noises)} q_sample draws, x_final |mean| {np.abs(t2n(samples)).mean():.4f}")
 
 
+def run_sampler_extras(cfg, W, out):
+    """The rest of DDIMSampler's surface on the reduced network (ddim_hacked.py:159-161, :237-318; util.py:49-50):
+    ucg_schedule, make_schedule(ddim_discretize='quad') + decode, encode (guidance 1), stochastic_encode."""
+    B, h, w = 2, 16, 16
+    model, cn, un = build_reference(cfg, W)
+    inp = W.synth_inputs(cfg, B, h, w, seed=41)
+    tt = {k: torch.from_numpy(v) for k, v in inp.items()}
+    cond = {"c_crossattn": [tt["ctx_cond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    uc = {"c_crossattn": [tt["ctx_uncond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    res = dict(B=B, h=h, w=w, seed=41)
+    with torch.no_grad():
+        s = make_sampler(model)
+        ucg = [9.0, 7.0, 5.0, 3.0, 1.5]
+        samples, inter = s.sample(5, B, (cfg.in_channels, h, w), cond, eta=0.0, x_T=tt["x_T"], unconditional_guidance_scale=7.5,
+                                  unconditional_conditioning=uc, log_every_t=1, verbose=False, ucg_schedule=ucg)
+        res["ucg_schedule"] = np.asarray(ucg, np.float32)
+        res["ucg_x_inter"] = np.stack([t2n(x) for x in inter["x_inter"]])
+        # quad grid: schedule scalars + a full decode from it with guidance
+        s = make_sampler(model)
+        s.make_schedule(6, ddim_discretize="quad", ddim_eta=0.0, verbose=False)
+        res["quad_timesteps"] = np.asarray(s.ddim_timesteps)
+        for name in ("ddim_alphas", "ddim_alphas_prev", "ddim_sigmas", "ddim_sqrt_one_minus_alphas"):
+            arr = getattr(s, name)
+            res["quad_" + name] = np.asarray([float(torch.full((1,), arr[i]).item()) for i in range(6)], np.float32)
+        res["quad_decode"] = t2n(s.decode(tt["x_T"], cond, 6, unconditional_guidance_scale=5.0, unconditional_conditioning=uc))
+        res["quad_decode_t4"] = t2n(s.decode(tt["x_T"], cond, 4, unconditional_guidance_scale=1.0, unconditional_conditioning=None))
+        # encode (uniform 5-step grid, guidance 1) and stochastic_encode
+        s = make_sampler(model)
+        s.make_schedule(5, ddim_eta=0.0, verbose=False)
+        g = np.random.default_rng(43)
+        x0 = torch.from_numpy(g.standard_normal((B, cfg.in_channels, h, w)).astype(np.float32))
+        nz = torch.from_numpy(g.standard_normal((B, cfg.in_channels, h, w)).astype(np.float32))
+        x_enc, info = s.encode(x0, cond, 4, return_intermediates=2)
+        res["enc_x0"], res["enc_out"] = t2n(x0), t2n(x_enc)
+        res["enc_inter"] = np.stack([t2n(x) for x in info["intermediates"]])
+        res["enc_inter_steps"] = np.asarray(info["intermediate_steps"], np.int64)
+        tq = torch.tensor([3, 1], dtype=torch.long)
+        res["senc_t"], res["senc_noise"] = tq.numpy(), t2n(nz)
+        res["senc_out"] = t2n(s.stochastic_encode(x0, tq, noise=nz))
+    np.savez_compressed(os.path.join(out, "sampler_extras_tiny.npz"), **res)
+    print("[golden] sampler_extras_tiny.npz: quad timesteps", res["quad_timesteps"])
+
+
 def run_clip_case(tag, cfg, W, B, out):
     """Cond-stage text transformer: the reference's FrozenCLIPEmbedder (ldm/modules/encoders/modules.py:88-131) wraps
     transformers' CLIPTextModel and returns `last_hidden_state`; the tokenizer/checkpoint cannot be fetched offline, so
@@ -431,6 +474,8 @@ def main():
     if want("clip"):
         run_clip_case("tiny_b3", W.TINY, W, 3, out)
         run_clip_case("sd15_b2", W.SD15, W, 2, out)
+    if want("extras"):
+        run_sampler_extras(W.TINY, W, out)
     if want("mask"):
         run_mask_case("tiny_mask_b2_16x16_s5", W.TINY, W, B=2, h=16, w=16, S=5, cfg_scale=7.5, out=out)
     if want("sd15") and not args.skip_sd15:

@@ -127,6 +127,32 @@ def test_inpainting_blend_matches_reference(golden_dir):
     assert relerr(samples, g["samples"]) < 1e-4
 
 
+def test_sampler_extras_match_reference(golden_dir):
+    """ucg_schedule, the 'quad' grid + decode, encode and stochastic_encode (ddim_hacked.py:159-161, :237-318; util.py:49-50)
+    of the reference sampler on the reduced network, replayed by the oracle."""
+    cfg = W.TINY
+    g = np.load(os.path.join(golden_dir, "sampler_extras_tiny.npz"))
+    B, h, w = int(g["B"]), int(g["h"]), int(g["w"])
+    inp = W.synth_inputs(cfg, B, h, w, seed=int(g["seed"]))
+    sd = W.synth_state_dict(cfg)
+    lay = O.make_layouts(cfg, W)
+    cond = dict(c_crossattn=inp["ctx_cond"], example_pair=inp["pair"], query=inp["query"])
+    unc = dict(c_crossattn=inp["ctx_uncond"], example_pair=inp["pair"], query=inp["query"])
+    _, x_inter, _ = O.ddim_sampling(sd, cfg, lay, 5, inp["x_T"], cond, unc, 7.5, ucg_schedule=list(g["ucg_schedule"]))
+    for i in range(6):
+        assert relerr(x_inter[i], g["ucg_x_inter"][i]) < 1e-4, i
+    ts = O.make_ddim_timesteps_quad(6)
+    np.testing.assert_array_equal(ts, g["quad_timesteps"])
+    sq = O.make_schedule(6, 0.0, timesteps=ts)
+    for k in ("ddim_alphas", "ddim_alphas_prev", "ddim_sigmas", "ddim_sqrt_one_minus_alphas"):
+        np.testing.assert_allclose(sq[k], g["quad_" + k], rtol=3e-7, atol=0, err_msg=k)
+    assert relerr(O.ddim_decode(sd, cfg, lay, sq, inp["x_T"], cond, unc, 6, 5.0), g["quad_decode"]) < 1e-4
+    assert relerr(O.ddim_decode(sd, cfg, lay, sq, inp["x_T"], cond, None, 4, 1.0), g["quad_decode_t4"]) < 1e-4
+    su = O.make_schedule(5, 0.0)
+    assert relerr(O.ddim_encode(sd, cfg, lay, su, g["enc_x0"], cond, 4), g["enc_out"]) < 1e-4
+    assert relerr(O.stochastic_encode(su, g["enc_x0"], g["senc_t"], g["senc_noise"]), g["senc_out"]) < 1e-6
+
+
 @pytest.mark.slow
 def test_sd15_config1_first_and_last_step(golden_dir):
     """BASELINE config #1 (256x256, 5 DDIM steps, bs 1): replay steps 0 and 4 of the reference
