@@ -73,7 +73,7 @@ def parity_leg(E, W, precision, stream_f32, device):
     kw = dict(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"], query=inp["query"],
               steps=S, cfg_scale=float(g["cfg_scale"]))
     ref = g["x_inter"]
-    steps = [0, 1, 2, 3, 4, 9, 19, 29, 39, 49]
+    steps = list(range(S))   # every step of the schedule
     e.sample_begin(**kw)
     rel, mabs = [], []
     for i in steps:
@@ -83,7 +83,7 @@ def parity_leg(E, W, precision, stream_f32, device):
         rel.append(float(d / np.abs(ref[i + 1]).max()))
         mabs.append(float(d))
     e.sample_end()
-    out = {"per_step_relerr": max(rel), "per_step_max_abs_err": max(mabs), "steps_checked": steps,
+    out = {"per_step_relerr": max(rel), "per_step_max_abs_err": max(mabs), "steps_checked": len(steps), "parity_ok": bool(max(rel) <= 1e-3),
            "schedule": "50-step DDIM, CFG 7.5, SD1.5 256x256 bs 1 (tests/golden/net_sd15_b1_32x32_s50.npz: the reference's CPU trajectory)",
            "bound": 1e-3, "mode": precision}
     if os.path.exists(f5):   # BASELINE config #1: the 5-step trajectory, whole loop from x_T
@@ -93,6 +93,10 @@ def parity_leg(E, W, precision, stream_f32, device):
         out["config1_per_step_relerr"] = max(float(np.abs(inter[i] - g5["x_inter"][i]).max() / np.abs(g5["x_inter"][i]).max())
                                              for i in range(1, int(g5["S"]) + 1))
         out["config1"] = "#1: 256x256, 5 DDIM steps, bs 1 (8x larger eps coefficient per step than the 50-step schedule)"
+        out["config1_parity_ok"] = bool(out["config1_per_step_relerr"] <= 1e-3)
+        # no 2-byte mode can meet 1e-3 on this schedule: rounding the WEIGHTS alone to fp16 already costs 8.5e-4 per step
+        # (error budget); the conforming mode for config #1 is f16x2 (<= 5e-6, reported under "f16x2")
+        out["config1_conforming_mode"] = "f16x2" if precision in ("f16", "bf16") else precision
     e.close()
     return out
 

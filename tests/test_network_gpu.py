@@ -210,30 +210,74 @@ def test_errors_are_reported_not_thrown(tiny_f32):
     e.close()
 
 
-@pytest.mark.parametrize("prec,tol_step,tol_eps", [("f32", 2e-4, 2e-4), ("f16x2", 1e-3, 2e-4), ("f16", 5e-3, 2.5e-3),
-                                                   ("bf16", 5e-2, 3e-2)])
-def test_sd15_config1(golden_dir, prec, tol_step, tol_eps):
-    """BASELINE config #1: SD1.5 + Prompt-Diffusion ControlNet, 256x256 (latent 32x32), 5 DDIM steps, bs 1,
-    against the trajectory the reference itself produced on CPU."""
+NORTH_STAR = 1e-3   # BASELINE.json: per-step latents within 1e-3 (relative) of the CPU reference
+
+
+def _config1_errors(golden_dir, prec, wround=None):
+    """BASELINE config #1 (SD1.5 + Prompt-Diffusion ControlNet, 256x256 = latent 32x32, 5 DDIM steps, bs 1, CFG 7.5) through the
+    engine; returns (eps error of one apply_model, control-tensor errors, per-step latent errors) against the trajectory the
+    reference itself produced on CPU.  wround="f16": weights pre-rounded to fp16 on the host (the fp32 engine then isolates the
+    weight-rounding share of the 2-byte modes' error)."""
     g = np.load(os.path.join(golden_dir, "net_sd15_b1_32x32_s5.npz"))
     cfg = W.SD15
-    e = _engine(cfg, prec)
+    e = E.Engine(cfg, precision=prec)
+    for n, a in W.iter_synth(cfg):
+        if wround == "f16" and a.ndim >= 2:
+            a = a.astype(np.float16).astype(np.float32)
+        e.load_tensor(n, a)
     inp, x_in, t_in, ctx, pair, qry = _cfg_inputs(cfg, g)
     eps, control = e.eps(x_in, t_in, ctx, pair, qry, return_control=True)
+    cerr = []
     for i, c in enumerate(control):
-        st = g[f"control_{i}_stats"]
         assert tuple(c.shape) == tuple(g[f"control_{i}_shape"])
         sub = c if f"control_{i}" in g else c.reshape(-1)[::int(g[f"control_{i}_stride"])][:4096]
         want = g[f"control_{i}"] if f"control_{i}" in g else g[f"control_{i}_sub"]
-        assert relerr(sub, want) < tol_eps, f"control {i}"
-    assert relerr(eps, g["eps"]) < tol_eps
+        cerr.append(relerr(sub, want))
     S = int(g["S"])
     out, inter = e.ddim_sample(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"],
                                query=inp["query"], steps=S, cfg_scale=float(g["cfg_scale"]), return_intermediates=True)
-    errs = [relerr(inter[i], g["x_inter"][i]) for i in range(S + 1)]
-    print(f"sd15 {prec} per-step latent relerr:", ["%.2e" % v for v in errs])
-    assert np.isfinite(out).all() and max(errs) < tol_step
     e.close()
+    assert np.isfinite(out).all()
+    errs = [relerr(inter[i], g["x_inter"][i]) for i in range(S + 1)]
+    print(f"sd15 config #1 {prec}{' + f16-rounded weights' if wround else ''} per-step latent relerr:", ["%.2e" % v for v in errs])
+    return relerr(eps, g["eps"]), cerr, errs
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
+def test_sd15_config1(golden_dir, prec):
+    """BASELINE config #1 at the north star's tolerance, in the modes that carry fp32-class operands (f16x2 is the conforming
+    mode of the 2-byte engine family: fp32 storage, every MFMA operand split into fp16 hi + lo)."""
+    eps_err, cerr, errs = _config1_errors(golden_dir, prec)
+    assert max(cerr) < 2e-4 and eps_err < 2e-4
+    assert max(errs) < NORTH_STAR
+    assert max(errs) < 2e-4     # in fact fp32-class
+
+
+def test_sd15_config1_weight_rounding_floor(golden_dir):
+    """Why no 2-byte mode can meet 1e-3 on THIS schedule: the fp32 engine fed weights rounded to fp16 -- every activation, every
+    accumulation and the whole residual stream exact -- is already at 8-9e-4 per step (CFG 7.5 multiplies the part of the
+    eps error that differs between the two passes; one 5-step DDIM step moves the latent by ~0.9 eps, against ~0.11 on the
+    50-step schedule the metric is quoted on).  Any rounding of an activation comes on top."""
+    _, _, errs = _config1_errors(golden_dir, "f32", wround="f16")
+    assert 5e-4 < max(errs) < NORTH_STAR
+
+
+@pytest.mark.parametrize("prec,tol_step,tol_eps", [("f16", 5e-3, 2.5e-3), ("bf16", 5e-2, 3e-2)])
+def test_sd15_config1_two_byte_modes_measured_bounds(golden_dir, prec, tol_step, tol_eps):
+    """The 2-byte modes on config #1, held to their measured bounds (fp16: weight rounding 8.5e-4 + activation rounding
+    3.6e-3 in quadrature; bf16: 8x both).  These are NOT the north-star tolerance: see the strict-xfail test below."""
+    eps_err, cerr, errs = _config1_errors(golden_dir, prec)
+    assert max(cerr) < tol_eps and eps_err < tol_eps
+    assert max(errs) < tol_step
+
+
+@pytest.mark.xfail(strict=True, reason="fp16 storage cannot meet 1e-3 per step on the 5-step schedule with CFG 7.5: weight rounding alone "
+                                       "is 8.5e-4 (test_sd15_config1_weight_rounding_floor), activation rounding adds 3.6e-3; the "
+                                       "conforming mode is f16x2 (test_sd15_config1). On the metric's own 50-step schedule f16 is "
+                                       "inside 1e-3 (test_sd15_headline_schedule_per_step).")
+def test_sd15_config1_f16_at_north_star(golden_dir):
+    _, _, errs = _config1_errors(golden_dir, "f16")
+    assert max(errs) < NORTH_STAR
 
 
 # one denoising step from the reference's own latent: what "per denoising step" means for the north-star bound
