@@ -244,10 +244,13 @@ def main():
         out = one_pass()
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [1e3 * dt / args.steps]
     if world > 1:
-        tmax = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        # MAX over ranks is the job's time; every rank's own time travels along so that a first real multi-GPU run diagnoses itself
+        tall = [torch.zeros(1, device="cpu" if rehearse else dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64))
+        rank_ms = [1e3 * float(t.item()) / args.steps for t in tall]
+        dt = max(float(t.item()) for t in tall)
     assert torch.isfinite(out).all(), "non-finite latents"
     images = world * B * args.steps
     value = images / dt
@@ -257,6 +260,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic", "rccl_ranks": world,
+        "backend": ("gloo (PD_BENCH_REHEARSE: every rank on device 0)" if rehearse else "nccl (RCCL)") if world > 1 else "none (single process)",
+        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "config": {"workload": f"SD1.5 UNet + Prompt-Diffusion ControlNet, {args.size}x{args.size}, {S}-step DDIM (eta 0), "
                                f"CFG 7.5, bs={B} per GPU (forward batch {2 * B}), random-init weights",
                    "global_batch": world * B, "latent": [h, w], "ddim_steps": S, "parallelism": f"batch-shard x{world}",

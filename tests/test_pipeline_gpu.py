@@ -162,8 +162,10 @@ def test_pipeline_custom_timesteps_and_leading_grid(eng):
     out3 = pipe(num_inference_steps=3, callback_on_step_end=lambda p, i, t, k: seen.append(int(t)) or {}, **kw).images
     assert seen == [667, 334, 1]                 # 3 steps, not the 4 of range(0, 1000, 333)
     np.testing.assert_array_equal(np.asarray(out3), np.asarray(pipe(timesteps=[667, 334, 1], **kw).images))
-    with pytest.raises(E.PdError, match="strictly descending"):
-        pipe(timesteps=[500, 500, 1], **kw)
+    with pytest.raises(E.PdError, match="must be descending"):
+        pipe(timesteps=[500, 600, 1], **kw)
+    # repeated timesteps are legal (make_ddim_timesteps('quad') produces them, util.py:50)
+    assert np.isfinite(np.asarray(pipe(timesteps=[667, 334, 334, 1], **kw).images)).all()
     from prompt_diffusion_amd.schedulers import UniPCMultistepScheduler
     with pytest.raises(ValueError, match="does not support custom"):
         PromptDiffusionPipeline(eng, scheduler=UniPCMultistepScheduler())(timesteps=ts, **kw)
