@@ -25,6 +25,22 @@
 
 namespace {
 
+// Diagnostic build only (tools/micro/st_stamp.hip compiles this file with -DPD_STAMP): s_memtime at the phase boundaries of wave 0 of
+// every workgroup, written to a buffer of its own.  No stamp executes in the product build.
+#ifdef PD_STAMP
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define PD_STAMP_AT(slot)                                                                                          \
+    do {                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        unsigned long long t_;                                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 16 + (slot)] = t_;                    \
+    } while (0)
+#else
+#define PD_STAMP_AT(slot) do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TC = 320;          // channels
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
     const int hh = lane >> 5;
     const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
 
+    PD_STAMP_AT(0);
     Pipe<0> pp;
     pp.wsrc = a.wpk;
     pp.kvsrc = a.kvp + (size_t)((blockIdx.x * 128) / a.rows_per_sample) * (4 * KV_PAIR * 1024);
@@ -254,6 +271,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
     pp.nxt = STEP_BYTES + pp.lane16;
     pp.w0 = ldsr(pp.cur); pp.w1 = ldsr(pp.cur + 1024); pp.w2 = ldsr(pp.cur + 2048); pp.w3 = ldsr(pp.cur + 3072);
 
+    PD_STAMP_AT(1);
     static_for<TNT>([&](auto TN) __attribute__((always_inline)) {
         constexpr int tn = decltype(TN)::value;
         run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
@@ -261,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
             return true;
         });
     });
+    PD_STAMP_AT(2);
 
     // ---- 2-5. cross-attention, two heads at a time
     ln_frags<P>(acc, yf);   // norm2 (gamma / beta live in the q weights / bias)
@@ -368,6 +387,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_BO2 + 32 * t + 16 * hh);
+    PD_STAMP_AT(3);
 
     // ---- 6-8. GEGLU feed-forward in chunks of 32 hidden units, software-pipelined: while the matrix pipe runs ff.net.0 of chunk
     // c + 1 ([x | gate] tiles, 40 MFMAs) the vector pipe does x * gelu(gate) of chunk c, 2 values per 5 MFMAs; then ff.net.2 of
@@ -420,6 +440,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
         });
     }
 
+    PD_STAMP_AT(4);
     // ---- 9. out = h3 . Wp^T + b + x_in
 #pragma unroll
     for (int t = 0; t < TNT; ++t) {
@@ -435,9 +456,11 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
             return true;
         });
     });
+    PD_STAMP_AT(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (clamped) requests must have landed before the LDS is released
 #pragma unroll
     for (int t = 0; t < TNT; ++t) store_row16<P, SF32>(a.out, (size_t)row * TC + 32 * t + 16 * hh, acc[t]);
+    PD_STAMP_AT(6);
 }
 
 
@@ -445,6 +468,40 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
 // h = proj_in(GroupNorm(x)) (attention.py:331-333; GroupNorm statistics arrive as per-(sample, channel) {scale, shift}), then
 // [q | k | v] = norm1(h) . Wqkv^T (attention.py:271: attn1 of norm1(x); gamma / beta folded into the weights / a bias).
 // Outputs: h [M][320] (the residual the tail kernel adds), q | k [M][640] row-major, V^T [B][320][vt_ld] for the attention kernel.
+
+// Two accumulator tiles (64 channels x the wave's 32 tokens) -> memory through a wave-private 4 KB LDS buffer, so that one store
+// instruction writes whole 128-byte row segments (8 rows x 128 B) instead of 64 16-byte pieces of 64 different lines.
+template <int P>
+__device__ __forceinline__ void store_rows64(unsigned buf, int lane, const f32x16& o0, const f32x16& o1, uint16_t* dst_row0, int ld_elems) {
+    const unsigned wa = buf + (lane & 31) * 128 + (lane >> 5) * 32;
+    *reinterpret_cast<uint4*>(smem + wa) = acc_frag<P, 0>(o0);
+    *reinterpret_cast<uint4*>(smem + wa + 16) = acc_frag<P, 1>(o0);
+    *reinterpret_cast<uint4*>(smem + wa + 64) = acc_frag<P, 0>(o1);
+    *reinterpret_cast<uint4*>(smem + wa + 80) = acc_frag<P, 1>(o1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = k * 64 + lane;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + buf + idx * 16);
+        *reinterpret_cast<uint4*>(dst_row0 + (size_t)(idx >> 3) * ld_elems + (idx & 7) * 8) = v;
+    }
+}
+// ... and transposed: [channel][32 tokens] rows of 64 bytes (V^T for the attention kernel)
+template <int P>
+__device__ __forceinline__ void store_cols64(unsigned buf, int lane, const f32x16& o0, const f32x16& o1, uint16_t* dst_ch0, int ld_elems) {
+    const unsigned wa = buf + ((lane >> 5) * 16) * 64 + (lane & 31) * 2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        *reinterpret_cast<uint16_t*>(smem + wa + r * 64) = cvt16<P>(o0[r]);
+        *reinterpret_cast<uint16_t*>(smem + wa + (32 + r) * 64) = cvt16<P>(o1[r]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = k * 64 + lane;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + buf + idx * 16);
+        *reinterpret_cast<uint4*>(dst_ch0 + (size_t)(idx >> 2) * ld_elems + (idx & 3) * 8) = v;
+    }
+}
+
 struct StFrontArgs {
     const void* x;        // [M][320] stream type
     const float* coef;    // [B][320][2] GroupNorm {scale, shift}
@@ -462,8 +519,8 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontArgs a) {
     const int hh = lane >> 5;
     const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
     const int sample = (blockIdx.x * 128) / a.rows_per_sample;
-    const int tok = row - sample * a.rows_per_sample;
 
+    PD_STAMP_AT(0);
     Pipe<1> pp;
     pp.wsrc = a.wpk;
     pp.kvsrc = a.wpk;
@@ -487,6 +544,7 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PD_STAMP_AT(1);
     // GroupNorm apply while the rows become B fragments: y = x * scale[c] + shift[c], rounded to the compute type like the
     // per-layer path's GroupNorm output
     uint4 yf[TKS];
@@ -516,23 +574,26 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontArgs a) {
             return true;
         });
     });
+    PD_STAMP_AT(2);
     // the residual stream is stored in the (2-byte) stream type; norm1 sees the same rounded values the per-layer path reads back
+    const unsigned sbuf = RING_BYTES + FV_TOTAL * 4 + wave * 4096;   // this wave's staging buffer for coalesced stores
+    const int row0 = blockIdx.x * 128 + wave * 32;
 #pragma unroll
     for (int t = 0; t < TNT; ++t) {
-        const uint4 lo = acc_frag<P, 0>(acc[t]), hi = acc_frag<P, 1>(acc[t]);
-        uint4* hp = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.h) + (size_t)row * TC + 32 * t + 16 * hh);
-        hp[0] = lo;
-        hp[1] = hi;
         float f[16];
-        unpack8<P>(lo, f);
-        unpack8<P>(hi, f + 8);
+        unpack8<P>(acc_frag<P, 0>(acc[t]), f);
+        unpack8<P>(acc_frag<P, 1>(acc[t]), f + 8);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = f[r];
     }
+#pragma unroll
+    for (int t = 0; t < TNT; t += 2)
+        store_rows64<P>(sbuf, lane, acc[t], acc[t + 1], reinterpret_cast<uint16_t*>(a.h) + (size_t)row0 * TC + 32 * t, TC);
     ln_frags<P>(acc, yf);   // norm1
+    PD_STAMP_AT(3);
     // q | k | v: 30 output tiles, one ring step each
-    uint16_t* qkrow = reinterpret_cast<uint16_t*>(a.qk) + (size_t)row * (2 * TC) + 16 * hh;
-    uint16_t* vtp = reinterpret_cast<uint16_t*>(a.vt) + ((size_t)sample * TC + 16 * hh) * a.vt_ld + tok;
+    uint16_t* qk0 = reinterpret_cast<uint16_t*>(a.qk) + (size_t)row0 * (2 * TC);
+    uint16_t* vt0 = reinterpret_cast<uint16_t*>(a.vt) + (size_t)sample * TC * a.vt_ld + (row0 - sample * a.rows_per_sample);
     for (int tg = 0; tg < 30; tg += 2) {   // two tiles per trip keeps the loop body at 40 MFMAs
         f32x16 o0 = lds_vec16(FV_BQKV + 32 * tg + 16 * hh), o1 = lds_vec16(FV_BQKV + 32 * (tg + 1) + 16 * hh);
         run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
@@ -543,21 +604,12 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontArgs a) {
             mfma32<P>(w, yf[decltype(I)::value], o1);
             return true;
         });
-        if (tg < 20) {
-            uint4* d0 = reinterpret_cast<uint4*>(qkrow + 32 * tg);
-            d0[0] = acc_frag<P, 0>(o0); d0[1] = acc_frag<P, 1>(o0);
-            d0[4] = acc_frag<P, 0>(o1); d0[5] = acc_frag<P, 1>(o1);
-        } else {
-            // V^T[sample][channel][token]: lanes 0..31 of a half wave are 32 consecutive tokens of one channel (64-byte runs)
-            uint16_t* v0 = vtp + (size_t)(32 * (tg - 20)) * a.vt_ld;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                v0[(size_t)r * a.vt_ld] = cvt16<P>(o0[r]);
-                v0[(size_t)(32 + r) * a.vt_ld] = cvt16<P>(o1[r]);
-            }
-        }
+        if (tg < 20) store_rows64<P>(sbuf, lane, o0, o1, qk0 + 32 * tg, 2 * TC);
+        else store_cols64<P>(sbuf, lane, o0, o1, vt0 + (size_t)(32 * (tg - 20)) * a.vt_ld, a.vt_ld);
     }
+    PD_STAMP_AT(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PD_STAMP_AT(5);
 }
 
 struct StFrontPackArgs { const uint16_t *wpi, *wqkv; int ld; uint16_t* dst; };
@@ -699,7 +751,7 @@ int launch_st_front(const void* x, const float* coef, void* h, void* qk, void* v
                     int vt_ld, int prec, hipStream_t s) {
     if (M % 128 || rows_per_sample % 128) return 1;
     StFrontArgs a{x, coef, h, qk, vt, reinterpret_cast<const char*>(wpk), vec, rows_per_sample, vt_ld};
-    constexpr int SMEM = RING_BYTES + FV_TOTAL * 4;
+    constexpr int SMEM = RING_BYTES + FV_TOTAL * 4 + 4 * 4096;
     static unsigned long long done[2] = {0, 0};
     void (*kfn)(StFrontArgs) = nullptr;
     int slot = 0;

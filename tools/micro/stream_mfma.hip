@@ -23,7 +23,7 @@ constexpr int SF = 20, NS = 6, D = 5;
 extern __shared__ __attribute__((aligned(16))) char smem[];
 __device__ __forceinline__ uint4 ldsr(unsigned addr) { return *reinterpret_cast<const uint4*>(smem + addr); }
 
-template <int MODE, bool BAR = true, bool READ = true, bool ONEW = false>
+template <int MODE, bool BAR = true, bool READ = true, bool ONEW = false, int SPREAD = 0>
 __global__ __launch_bounds__(256, 1) void k(const char* __restrict__ w, int nsteps_stream, const uint4* __restrict__ x, float* out, int iters,
                                               unsigned long long* stamps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -35,6 +35,12 @@ __global__ __launch_bounds__(256, 1) void k(const char* __restrict__ w, int nste
     for (int t = 0; t < 10; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const char* src = w + lane * 16;
     int step = 0;
+    auto issue1 = [&](int st, int q) __attribute__((always_inline)) {   // one of the 5 pieces of this wave
+        const unsigned slot = (unsigned)st % NS;
+        const int ss = st % nsteps_stream;
+        const int f = q * 4 + wave;
+        glds16(src + ((size_t)ss * SF + f) * 1024, __builtin_amdgcn_readfirstlane((slot * SF + f) * 1024));
+    };
     auto issue = [&](int st) __attribute__((always_inline)) {
         const unsigned slot = (unsigned)st % NS;
         const int ss = st % nsteps_stream;
@@ -73,10 +79,11 @@ __global__ __launch_bounds__(256, 1) void k(const char* __restrict__ w, int nste
                     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+                if constexpr (MODE == 2 && SPREAD > 0 && f > 9 && (f - 9) % SPREAD == 0 && (f - 9) / SPREAD < 5) issue1(step + D, (f - 9) / SPREAD);
                 if constexpr (MODE == 2 && f == 9) {
                     if constexpr (ONEW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
                     if constexpr (BAR) __builtin_amdgcn_s_barrier();
-                    issue(step + D);
+                    if constexpr (SPREAD == 0) issue(step + D); else issue1(step + D, 0);
                 }
             });
             step++;
@@ -154,10 +161,10 @@ __global__ __launch_bounds__(256, 1) void k3(const char* __restrict__ w, int nst
     if (threadIdx.x == 0) { stamps[blockIdx.x * 2] = t1 - t0; stamps[blockIdx.x * 2 + 1] = r1 - r0; }
 }
 
-template <int MODE, bool BAR = true, bool READ = true, bool ONEW = false>
+template <int MODE, bool BAR = true, bool READ = true, bool ONEW = false, int SPREAD = 0>
 void run(const char* w, int nsteps_stream, const uint4* x, float* out, unsigned long long* st, int blocks, int iters) {
     const int smem_bytes = NS * SF * 1024;
-    auto kf = k<MODE == 3 ? 2 : MODE, BAR, READ, ONEW>;
+    auto kf = k<MODE == 3 ? 2 : MODE, BAR, READ, ONEW, SPREAD>;
     if constexpr (MODE == 3) kf = k3;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     hipEvent_t e0, e1;
@@ -177,7 +184,7 @@ void run(const char* w, int nsteps_stream, const uint4* x, float* out, unsigned 
     clk /= blocks; cyc /= blocks;
     const double mfmas = (double)iters * 200.0;
     const double flops = (double)blocks * 4 * mfmas * 32768.0;
-    printf("mode %d bar %d read %d onew %d blocks %4d stream %5.2f MB: %8.3f ms  %6.0f TF/s  clock %4.0f MHz  %.1f cycles/MFMA in-kernel  (L2->LDS %.1f TB/s)\n", MODE, (int)BAR, (int)READ, (int)ONEW, blocks,
+    printf("mode %d bar %d read %d onew %d spread %d blocks %4d stream %5.2f MB: %8.3f ms  %6.0f TF/s  clock %4.0f MHz  %.1f cycles/MFMA in-kernel  (L2->LDS %.1f TB/s)\n", MODE, (int)BAR, (int)READ, (int)ONEW, SPREAD, blocks,
            nsteps_stream * 20.0 / 1024, ms, flops / ms / 1e9, clk, cyc / mfmas, MODE >= 2 ? (double)blocks * mfmas * 1024 / ms / 1e9 : 0.0);
 }
 
@@ -192,15 +199,10 @@ int main() {
     const int iters = 16;   // 3200 MFMAs per wave ~ one st_tail workgroup
     run<0>(w, 160, x, out, st, 256, iters);
     run<1>(w, 160, x, out, st, 256, iters);
-    run<2>(w, 160, x, out, st, 256, iters);    // 3.1 MB stream: the transformer tail's weights
+    run<2>(w, 160, x, out, st, 512, iters);                              // burst of 5 LDS-DMAs per wave behind the barrier
+    run<2, true, true, false, 1>(w, 160, x, out, st, 512, iters);       // one LDS-DMA per MFMA after the barrier
+    run<2, true, true, false, 2>(w, 160, x, out, st, 512, iters);       // one every 2 MFMAs
     run<2>(w, 160, x, out, st, 512, iters);
-    run<2>(w, 3200, x, out, st, 512, iters);   // 62.5 MB: beyond L2, Infinity-Cache resident
-    run<3>(w, 160, x, out, st, 256, iters);
-    run<3>(w, 160, x, out, st, 512, iters);
-    run<3>(w, 3200, x, out, st, 512, iters);
-    run<2, false, true>(w, 160, x, out, st, 256, iters);    // no barrier (timing only)
-    run<2, true, false>(w, 160, x, out, st, 256, iters);    // LDS-DMA + barrier, no fragment reads
-    run<2, false, false>(w, 160, x, out, st, 256, iters);   // LDS-DMA only
-    run<2, true, true, true>(w, 160, x, out, st, 256, iters);   // one wave issues a whole step
+    run<2, true, true, false, 2>(w, 160, x, out, st, 512, iters);
     return 0;
 }
