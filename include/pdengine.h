@@ -243,9 +243,9 @@ int pd_bench_linear(pd_engine* e, int32_t M, int32_t K, int32_t N, int32_t resid
  *     CFG + scheduler.step (FlowMatchEuler)                  promptdiffusioncontrolnetpipeline_sd3.py:1237-1243
  * The block arithmetic lives in diffusers (absent offline): PARITY UNPINNED, checked against oracle/sd3_oracle.py only.
  * Parameter names are diffusers' state-dict names under the prefixes "transformer." (SD3Transformer2DModel) and
- * "controlnet." (SD3PromptDiffusionModel).  The example-pair / query conditions arrive as VAE latents: down_proj and
- * vae.encode (encode_support_pair, promptdiffusioncontrolnet_sd3.py:189-198) stay with the caller.
- * Not built: qk_norm, dual_attention_layers (SD3.5), joint_attention_kwargs / LoRA scale. */
+ * "controlnet." (SD3PromptDiffusionModel).  The example-pair / query conditions arrive as VAE latents: pd_sd3_down_proj is the
+ * Conv2d(6, 3) half of encode_support_pair (promptdiffusioncontrolnet_sd3.py:189-198); vae.encode stays with the caller.
+ * Not built: the SD3SingleTransformerBlock branch (joint_attention_dim = None, :147-160), joint_attention_kwargs / LoRA scale. */
 typedef struct pd_sd3_config {
     int32_t in_channels;        /* 16 */
     int32_t out_channels;       /* 16 */
@@ -260,7 +260,12 @@ typedef struct pd_sd3_config {
     int32_t cn_pos_embed_max_size; /* the ControlNet's own table (promptdiffusioncontrolnet_sd3.py:102 default 96); 0: same */
     int32_t cn_zero_pooled;     /* force_zeros_for_pooled_projection (promptdiffusioncontrolnet_sd3.py:108, pipeline :1164-1168):
                                    the ControlNet sees zero pooled projections; 0: cn_pooled, or pooled when that is NULL */
-    int32_t reserved[4];
+    int32_t qk_norm;            /* 0: none; 1: "rms_norm" -- RMSNorm(head_dim, eps 1e-6) on the queries and keys of every head
+                                   (attn.norm_q / norm_k / norm_added_q / norm_added_k), promptdiffusioncontrolnet_sd3.py:105,140 */
+    uint32_t dual_mask;         /* bit i: transformer block i carries attn2, a second attention over the image tokens alone
+                                   (dual_attention_layers, :104,141; norm1.linear then has 9 chunks) */
+    uint32_t cn_dual_mask;      /* the same for the ControlNet's blocks */
+    int32_t reserved[1];
 } pd_sd3_config;
 
 typedef struct pd_sd3_args {
@@ -296,6 +301,9 @@ int pd_sd3_control(pd_engine* e, const pd_sd3_args* args, int32_t index, float* 
  * ControlNet (its residuals would be all zero).  latents_out: [B, C, H, W]. */
 int pd_sd3_sample(pd_engine* e, const pd_sd3_args* args, const float* sigmas, int32_t steps, float guidance,
                   const float* step_scales, float* latents_out);
+/* SD3PromptDiffusionModel.down_proj (promptdiffusioncontrolnet_sd3.py:114, :189-194): Conv2d(6, 3, kernel 3, padding 1) over
+ * pair = cat([cond, gt], 1) [B, 6, H, W] -> out [B, 3, H, W] (fp32, `mem` as in pd_sd3_args). */
+int pd_sd3_down_proj(pd_engine* e, const float* pair, int32_t B, int32_t H, int32_t W, int32_t mem, float* out);
 
 #ifdef __cplusplus
 }

@@ -124,7 +124,15 @@ def attention(q, k, v, heads):
     return np.einsum("bhij,bhjd->bhid", a, sp(v)).transpose(0, 2, 1, 3).reshape(B, Nq, D).astype(F32)
 
 
-def joint_block(sd, pre, cfg, x, c, temb, context_pre_only, fp8=False):
+def rms_norm_heads(t, w, heads, eps=1e-6):
+    """RMSNorm(dim_head, eps=1e-6, elementwise_affine=True) on every head of a [B, N, heads * dim_head] projection (qk_norm="rms_norm")."""
+    B, N, D = t.shape
+    x = t.reshape(B, N, heads, D // heads)
+    y = x / np.sqrt((x * x).mean(-1, keepdims=True) + F32(eps)) * w
+    return y.reshape(B, N, D).astype(F32)
+
+
+def joint_block(sd, pre, cfg, x, c, temb, context_pre_only, fp8=False, dual=False):
     """JointTransformerBlock: AdaLN-Zero on both streams, attention over [image ; context] tokens, gated residuals.
     fp8: the engine's sd3_fp8 option (0 / False, 1, 2) -- the projections fed by an AdaLN output (q/k/v of both streams,
     ff / ff_context net.0) take e4m3 operands (linear_fp8); level 2 also the feed-forward-out projections (ff_fp8_bounded)."""
@@ -133,8 +141,13 @@ def joint_block(sd, pre, cfg, x, c, temb, context_pre_only, fp8=False):
     qlinear = linear_fp8 if fp8 else linear
     e = silu(temb)
     m = linear(e, P("norm1.linear.weight"), P("norm1.linear.bias"))
-    sh_a, sc_a, g_a, sh_m, sc_m, g_m = np.split(m, 6, axis=-1)
+    if dual:    # SD35AdaLayerNormZeroX: 9 chunks, the last three modulate the image-only second attention (attn2)
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m, sh_a2, sc_a2, g_a2 = np.split(m, 9, axis=-1)
+        xn_2 = layer_norm_noaffine(x) * (1 + sc_a2[:, None]) + sh_a2[:, None]
+    else:
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = np.split(m, 6, axis=-1)
     xn = layer_norm_noaffine(x) * (1 + sc_a[:, None]) + sh_a[:, None]
+    qkn = getattr(cfg, "qk_norm", None) == "rms_norm"
     mc = linear(e, P("norm1_context.linear.weight"), P("norm1_context.linear.bias"))
     if context_pre_only:      # AdaLayerNormContinuous: chunk order (scale, shift)
         c_sc, c_sh = np.split(mc, 2, axis=-1)
@@ -143,15 +156,23 @@ def joint_block(sd, pre, cfg, x, c, temb, context_pre_only, fp8=False):
         c_sh_a, c_sc_a, c_g_a, c_sh_m, c_sc_m, c_g_m = np.split(mc, 6, axis=-1)
         cn = layer_norm_noaffine(c) * (1 + c_sc_a[:, None]) + c_sh_a[:, None]
     N = x.shape[1]
-    q = np.concatenate([qlinear(xn, P("attn.to_q.weight"), P("attn.to_q.bias")),
-                        qlinear(cn, P("attn.add_q_proj.weight"), P("attn.add_q_proj.bias"))], axis=1)
-    k = np.concatenate([qlinear(xn, P("attn.to_k.weight"), P("attn.to_k.bias")),
-                        qlinear(cn, P("attn.add_k_proj.weight"), P("attn.add_k_proj.bias"))], axis=1)
+    qx, qc = qlinear(xn, P("attn.to_q.weight"), P("attn.to_q.bias")), qlinear(cn, P("attn.add_q_proj.weight"), P("attn.add_q_proj.bias"))
+    kx, kc = qlinear(xn, P("attn.to_k.weight"), P("attn.to_k.bias")), qlinear(cn, P("attn.add_k_proj.weight"), P("attn.add_k_proj.bias"))
+    if qkn:     # per-head RMSNorm of queries and keys, own weights per stream
+        qx, kx = rms_norm_heads(qx, P("attn.norm_q.weight"), cfg.heads), rms_norm_heads(kx, P("attn.norm_k.weight"), cfg.heads)
+        qc, kc = rms_norm_heads(qc, P("attn.norm_added_q.weight"), cfg.heads), rms_norm_heads(kc, P("attn.norm_added_k.weight"), cfg.heads)
+    q, k = np.concatenate([qx, qc], axis=1), np.concatenate([kx, kc], axis=1)
     v = np.concatenate([qlinear(xn, P("attn.to_v.weight"), P("attn.to_v.bias")),
                         qlinear(cn, P("attn.add_v_proj.weight"), P("attn.add_v_proj.bias"))], axis=1)
     o = attention(q, k, v, cfg.heads)
     ox = linear(o[:, :N], P("attn.to_out.0.weight"), P("attn.to_out.0.bias"))
     x = x + g_a[:, None] * ox
+    if dual:    # attn2: self-attention over the image tokens alone, on the second modulated copy of the block input
+        q2, k2 = linear(xn_2, P("attn2.to_q.weight"), P("attn2.to_q.bias")), linear(xn_2, P("attn2.to_k.weight"), P("attn2.to_k.bias"))
+        if qkn:
+            q2, k2 = rms_norm_heads(q2, P("attn2.norm_q.weight"), cfg.heads), rms_norm_heads(k2, P("attn2.norm_k.weight"), cfg.heads)
+        o2 = attention(q2, k2, linear(xn_2, P("attn2.to_v.weight"), P("attn2.to_v.bias")), cfg.heads)
+        x = x + g_a2[:, None] * linear(o2, P("attn2.to_out.0.weight"), P("attn2.to_out.0.bias"))
     xn2 = layer_norm_noaffine(x) * (1 + sc_m[:, None]) + sh_m[:, None]
     if fp8 >= 2:
         ff = ff_fp8_bounded(xn2, P("ff.net.0.proj.weight"), P("ff.net.0.proj.bias"), P("ff.net.2.weight"), P("ff.net.2.bias"))
@@ -196,7 +217,8 @@ def controlnet_forward(sd, cfg, x, t, ctx, pooled, cond, pair, scale=1.0, prefix
     hs = (hs + patch_embed(cond, pi_w, pi_b, cfg.patch) + patch_embed(pair, pi_w, pi_b, cfg.patch)).astype(F32)   # :440
     res = []
     for i in range(cfg.cn_layers):
-        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, False, fp8)
+        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, False, fp8,
+                            dual=i in tuple(getattr(cfg, "cn_dual_attention_layers", ())))
         res.append(hs)
     return [(linear(r, P(f"controlnet_blocks.{i}.weight"), P(f"controlnet_blocks.{i}.bias")) * F32(scale)).astype(F32)
             for i, r in enumerate(res)]
@@ -214,7 +236,8 @@ def transformer_forward(sd, cfg, x, t, ctx, pooled, control=None, prefix="transf
     interval_control = cfg.layers / len(control) if control else 0.0     # float division, as SD3Transformer2DModel.forward does
     for i in range(cfg.layers):
         last = i == cfg.layers - 1
-        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, last, fp8)
+        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, last, fp8,
+                            dual=i in tuple(getattr(cfg, "dual_attention_layers", ())))
         if control and not last:
             hs = (hs + control[int(i / interval_control)]).astype(F32)
     m = linear(silu(temb), P("norm_out.linear.weight"), P("norm_out.linear.bias"))
@@ -224,6 +247,18 @@ def transformer_forward(sd, cfg, x, t, ctx, pooled, control=None, prefix="transf
     p, Co = cfg.patch, cfg.out_channels
     out = out.reshape(B, h, w, p, p, Co).transpose(0, 5, 1, 3, 2, 4).reshape(B, Co, h * p, w * p)   # nhwpqc -> nchpwq
     return out.astype(F32)
+
+
+def down_proj(sd, pair, prefix="controlnet."):
+    """encode_support_pair without a VAE (promptdiffusioncontrolnet_sd3.py:189-198): Conv2d(6, 3, 3, padding=1) over cat([cond, gt], 1)."""
+    w, b = sd[prefix + "down_proj.weight"], sd[prefix + "down_proj.bias"]
+    B, C, H, W = pair.shape
+    xp = np.pad(pair, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    out = np.zeros((B, w.shape[0], H, W), F32)
+    for ky in range(3):
+        for kx in range(3):
+            out += np.einsum("bchw,oc->bohw", xp[:, :, ky:ky + H, kx:kx + W], w[:, :, ky, kx])
+    return (out + b[None, :, None, None]).astype(F32)
 
 
 def flow_match_sigmas(steps, shift=3.0, num_train=1000):

@@ -290,6 +290,10 @@ int launch_adaln(const void* x, int x_dt, void* y, int y_dt, const float* mod, i
                  float* bound_out = nullptr, float bound_mul = 0.f, float bound_add = 0.f);   // bound_out[row] = |y_row|_2 * mul + add
 // max over rows of the row L2 norm of W (dtype dt, row stride ld) and max |bias| -> out[0], out[1] (fp32, device, zeroed by the caller)
 int launch_rows_norm_max(const void* W, int dt, int ld, const float* bias, int rows, int K, float* out, hipStream_t s);
+// per-head RMSNorm (qk_norm = "rms_norm") of the q and k halves of a [rows][2 * heads * dh] buffer, in place: row r of sample b uses (wq, wk) when
+// its token index < n_first, else (wq2, wk2) (the context stream's norm_added_q / norm_added_k); dh <= 64, dh % 8 == 0
+int launch_qk_rmsnorm(void* qk, int dt, long long rows, int rows_per_sample, int n_first, int heads, int dh, const float* wq, const float* wk,
+                      const float* wq2, const float* wk2, float eps, hipStream_t s);
 int launch_patchify(const float* nchw, void* out, int out_dt, int B, int C, int H, int W, int patch, int Cpad, int Kpad, hipStream_t s);
 // Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0) of B <= 64 host-side timesteps: out[b] = [cos(t f_i) | sin(t f_i)],
 // f_i = exp(-ln(10000) i / 128); the values are passed by value (no host buffer has to outlive the launch)

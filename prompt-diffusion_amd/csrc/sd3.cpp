@@ -14,6 +14,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <string>
 
 #include "engine.h"
 
@@ -36,7 +37,12 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
     patch(net.pe, "pos_embed.proj");
     reg_vec(P + "pos_embed.pos_embed", net.pos_max * net.pos_max * D, &net.pos, 'b');
     params.back().shape = {1, (int64_t)net.pos_max * net.pos_max, D};
-    if (controlnet) patch(net.pe_in, "pos_embed_input.proj");
+    if (controlnet) {
+        patch(net.pe_in, "pos_embed_input.proj");
+        build_conv(P + "down_proj.", net.down_proj, 6, 3, 3, 1);   // encode_support_pair's Conv2d(6, 3, 3, padding=1), :114
+    }
+    const uint32_t dual_mask = controlnet ? sd3.cn_dual_mask : sd3.dual_mask;
+    const int hd = sd3.head_dim;
     lin(net.t1, "time_text_embed.timestep_embedder.linear_1", D, 256);
     lin(net.t2, "time_text_embed.timestep_embedder.linear_2", D, D);
     lin(net.p1, "time_text_embed.text_embedder.linear_1", D, sd3.pooled_dim);
@@ -48,7 +54,8 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
     for (int i = 0; i < net.layers; ++i) {
         Sd3BlockW& b = net.blocks[i];
         b.pre_only = !controlnet && i == net.layers - 1;
-        b.mod_off = rows; rows += 6 * D;
+        b.dual = i < 32 && ((dual_mask >> i) & 1u) && !b.pre_only;
+        b.mod_off = rows; rows += (b.dual ? 9 : 6) * D;
         b.mod_c_off = rows; rows += (b.pre_only ? 2 : 6) * D;
     }
     if (!controlnet) { net.norm_out_off = rows; rows += 2 * D; }
@@ -57,8 +64,8 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
     for (int i = 0; i < net.layers; ++i) {
         Sd3BlockW& b = net.blocks[i];
         const std::string Bp = P + "transformer_blocks." + std::to_string(i) + ".";
-        reg_mat(Bp + "norm1.linear.weight", {6 * D, D}, &net.mod, b.mod_off, false);
-        reg_bias(Bp + "norm1.linear.bias", &net.mod, b.mod_off, 6 * D);
+        reg_mat(Bp + "norm1.linear.weight", {(b.dual ? 9 : 6) * D, D}, &net.mod, b.mod_off, false);
+        reg_bias(Bp + "norm1.linear.bias", &net.mod, b.mod_off, (b.dual ? 9 : 6) * D);
         const int nc = (b.pre_only ? 2 : 6) * D;
         reg_mat(Bp + "norm1_context.linear.weight", {nc, D}, &net.mod, b.mod_c_off, false);
         reg_bias(Bp + "norm1_context.linear.bias", &net.mod, b.mod_c_off, nc);
@@ -73,6 +80,24 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
             reg_bias(Bp + "attn." + nmc[j] + ".bias", &b.qkv_c, j * D, D);
         }
         lin(b.out, "transformer_blocks." + std::to_string(i) + ".attn.to_out.0", D, D);
+        if (sd3.qk_norm) {
+            reg_vec(Bp + "attn.norm_q.weight", hd, &b.nq, 'g');
+            reg_vec(Bp + "attn.norm_k.weight", hd, &b.nk, 'g');
+            reg_vec(Bp + "attn.norm_added_q.weight", hd, &b.naq, 'g');
+            reg_vec(Bp + "attn.norm_added_k.weight", hd, &b.nak, 'g');
+        }
+        if (b.dual) {
+            make_mat(b.qkv2, 3 * D, D, 1, D, true);
+            for (int j = 0; j < 3; ++j) {
+                reg_mat(Bp + "attn2." + nm[j] + ".weight", {D, D}, &b.qkv2, j * D, false);
+                reg_bias(Bp + "attn2." + nm[j] + ".bias", &b.qkv2, j * D, D);
+            }
+            lin(b.out2, "transformer_blocks." + std::to_string(i) + ".attn2.to_out.0", D, D);
+            if (sd3.qk_norm) {
+                reg_vec(Bp + "attn2.norm_q.weight", hd, &b.nq2, 'g');
+                reg_vec(Bp + "attn2.norm_k.weight", hd, &b.nk2, 'g');
+            }
+        }
         lin(b.ff1, "transformer_blocks." + std::to_string(i) + ".ff.net.0.proj", 4 * D, D);
         lin(b.ff2, "transformer_blocks." + std::to_string(i) + ".ff.net.2", D, 4 * D);
         if (!b.pre_only) {
@@ -203,6 +228,21 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     PD_TRY(adaln(x, xn, b.mod_off, b.mod_off + D, xs, pre_add ? pre_add->p : nullptr));   // (shift_msa, scale_msa, gate_msa, shift_mlp, ...)
     if (b.pre_only) PD_TRY(adaln(c, cn, b.mod_c_off + D, b.mod_c_off, cs));     // AdaLayerNormContinuous: (scale, shift)
     else PD_TRY(adaln(c, cn, b.mod_c_off, b.mod_c_off + D, cs));
+    // dual_attention_layers: the second modulated copy of the block INPUT (chunks 6 / 7 of SD35AdaLayerNormZeroX) for attn2
+    Act xn2;
+    if (b.dual) {
+        xn2 = new_act(B, N, 1, D, T);
+        PD_TRY(adaln(x, xn2, b.mod_off + 6 * D, b.mod_off + 7 * D, nullptr));
+    }
+    auto qk_norm = [&](const Act& buf, int rows_per_sample, int n_first, const float* wq, const float* wk, const float* wq2, const float* wk2) -> int {
+        if (!sd3.qk_norm || arena.dry) return 0;
+        ++launches;
+        if (launch_qk_rmsnorm(buf.p, T, (long long)B * rows_per_sample, rows_per_sample, n_first, heads, D / heads, wq, wk, wq2, wk2, 1e-6f, stream)) {
+            pd_set_error("sd3: qk RMSNorm launch failed");
+            return 1;
+        }
+        return 0;
+    };
     // both QKV GEMMs store straight into the joint buffers
     {
         Act o = qk; o.H = N;
@@ -212,6 +252,7 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
         gx.c_sample_rows = Nt; gx.c_row_off = N; gx.vt_tok_off = N; gx.a_scale = cs;
         PD_TRY(gemm(b.qkv_c, cn, o, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * D, vt_ld));
     }
+    PD_TRY(qk_norm(qk, Nt, N, b.nq, b.nk, b.naq, b.nak));   // per-head RMSNorm of q and k, own weights per stream
     // ONE attention launch over the joint sequence (image queries only in the context_pre_only block); the out-projections
     // read their token stream out of the joint output through the A-row remap
     const char* qkp = reinterpret_cast<const char*>(qk.p);
@@ -224,6 +265,17 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     if (!b.pre_only) {
         gx.gate = mod + b.mod_c_off + 2 * D; gx.gate_stride = ms; gx.a_sample_rows = Nt; gx.a_row_off = N;
         PD_TRY(gemm(b.out_c, att, c, 1, 0, 0, 1.f, &c, nullptr, 0, false, nullptr, 0, 0));
+    }
+    if (b.dual) {   // x += gate_msa2 * attn2(norm_hidden_states2): self-attention over the image tokens alone
+        const int vl2 = round_up(N, 8);
+        Act qk2 = new_act(B, N, 1, 2 * D, T), vt2 = new_act(B, D, 1, vl2, T), att2 = new_act(B, N, 1, D, T);
+        if (!arena.dry && vl2 != N) HIP_OK(hipMemsetAsync(vt2.p, 0, vt2.bytes(), stream));
+        PD_TRY(gemm(b.qkv2, xn2, qk2, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt2.p, 2 * D, vl2));
+        PD_TRY(qk_norm(qk2, N, N, b.nq2, b.nk2, nullptr, nullptr));
+        const char* q2p = reinterpret_cast<const char*>(qk2.p);
+        PD_TRY(attention(q2p, 2 * D, q2p + (size_t)D * eb, 2 * D, vt2.p, vl2, att2.p, D, B, N, N, D, heads));
+        gx.gate = mod + b.mod_off + 8 * D; gx.gate_stride = ms;
+        PD_TRY(gemm(b.out2, att2, x, 1, 0, 0, 1.f, &x, nullptr, 0, false, nullptr, 0, 0));
     }
     arena.release(mk);
     // feed-forward of each stream
@@ -617,4 +669,40 @@ extern "C" int pd_sd3_sample(pd_engine* e, const pd_sd3_args* a, const float* si
     PD_TRY(sd3_check(e, a, false));
     if (!sigmas || steps < 1 || !latents_out) { pd_set_error("pd_sd3_sample: sigmas, steps >= 1 and latents_out are required"); return 1; }
     return sd3_run(e, a, sigmas, steps, guidance, step_scales, -1, latents_out);
+}
+
+// SD3PromptDiffusionModel.down_proj, promptdiffusioncontrolnet_sd3.py:114,189-194: Conv2d(6, 3, 3, padding=1) on the example pair
+extern "C" int pd_sd3_down_proj(pd_engine* e, const float* pair, int32_t B, int32_t H, int32_t W, int32_t mem, float* out) {
+    if (!e || !pair || !out || B < 1 || H < 1 || W < 1) { pd_set_error("pd_sd3_down_proj: bad argument"); return 1; }
+    if (!e->sd3_cn.built) { pd_set_error("pd_sd3_down_proj: this engine has no SD3 ControlNet"); return 1; }
+    for (auto& p : e->params)
+        if (p.group == 3 && !p.loaded && p.name.find("down_proj") != std::string::npos) { pd_set_error("weights not loaded: '%s'", p.name.c_str()); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    const ConvW& c = e->sd3_cn.down_proj;
+    const size_t n_in = (size_t)B * 6 * H * W, n_out = (size_t)B * 3 * H * W, px = (size_t)B * H * W;
+    const int T = e->T;
+    float *din = nullptr, *dout = nullptr;
+    void *xin = nullptr, *y = nullptr;
+    int r = 1;
+    do {
+        if (hipMalloc(&din, n_in * 4) != hipSuccess || hipMalloc(&dout, n_out * 4) != hipSuccess ||
+            hipMalloc(&xin, px * 8 * dt_size(T)) != hipSuccess || hipMalloc(&y, px * 4 * 4) != hipSuccess) { pd_set_error("pd_sd3_down_proj: allocation failed"); break; }
+        if (hipMemcpyAsync(din, pair, n_in * 4, mem == PD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream) != hipSuccess) break;
+        if (launch_nchw_to_nhwc(din, xin, T, B, 6, H, W, 8, e->stream)) break;
+        Act a, o;
+        a.p = xin; a.B = B; a.H = H; a.W = W; a.C = 8; a.dt = T;
+        o.p = y; o.B = B; o.H = H; o.W = W; o.C = 4; o.dt = DT_F32;
+        const Arena saved = e->arena;
+        e->arena = Arena{};     // no split-K workspace: the conv runs as one plain launch
+        const int rc = e->conv(c, a, o);
+        e->arena = saved;
+        if (rc) break;
+        if (launch_nhwc_to_nchw(y, DT_F32, dout, B, 3, H, W, 4, 1.f, e->stream)) break;
+        if (hipMemcpyAsync(out, dout, n_out * 4, mem == PD_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream) != hipSuccess) break;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) break;
+        r = 0;
+    } while (0);
+    if (r) pd_set_error("pd_sd3_down_proj failed: %s", hipGetErrorString(hipGetLastError()));
+    hipFree(din); hipFree(dout); hipFree(xin); hipFree(y);
+    return r;
 }

@@ -415,3 +415,61 @@ int launch_timestep_embedding(const float* t_host, int B, float* out, hipStream_
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3(B), dim3(128), 0, s, a, out);
     return hipGetLastError() != hipSuccess;
 }
+// qk_norm = "rms_norm": one thread per (row, head, q|k) group of dh <= 64 values of the joint q|k buffer
+template <int DT>
+__global__ __launch_bounds__(256) void qk_rmsnorm_kernel(void* __restrict__ qk, long long rows, int rows_per_sample, int n_first, int heads, int dh,
+                                                         const float* __restrict__ wq, const float* __restrict__ wk,
+                                                         const float* __restrict__ wq2, const float* __restrict__ wk2, float eps) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = rows * heads * 2;
+    if (gid >= total) return;
+    const int which = (int)(gid % 2), head = (int)((gid / 2) % heads);
+    const long long row = gid / (2LL * heads);
+    const int tok = (int)(row % rows_per_sample);
+    const float* w = tok < n_first ? (which ? wk : wq) : (which ? wk2 : wq2);
+    uint16_t* p = reinterpret_cast<uint16_t*>(qk) + (size_t)row * (2 * heads * dh) + (size_t)which * heads * dh + (size_t)head * dh;
+    float v[64];
+    float ss = 0.f;
+    for (int i = 0; i < dh; i += 8) {
+        float f[8];
+        unpack8<DT>(*reinterpret_cast<const uint4*>(p + i), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[i + j] = f[j]; ss = fmaf(f[j], f[j], ss); }
+    }
+    const float r = 1.0f / sqrtf(ss / (float)dh + eps);
+    for (int i = 0; i < dh; i += 8) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = v[i + j] * r * w[i + j];
+        *reinterpret_cast<uint4*>(p + i) = pack8<DT>(f);
+    }
+}
+__global__ __launch_bounds__(256) void qk_rmsnorm_f32_kernel(float* __restrict__ qk, long long rows, int rows_per_sample, int n_first, int heads, int dh,
+                                                             const float* __restrict__ wq, const float* __restrict__ wk,
+                                                             const float* __restrict__ wq2, const float* __restrict__ wk2, float eps) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = rows * heads * 2;
+    if (gid >= total) return;
+    const int which = (int)(gid % 2), head = (int)((gid / 2) % heads);
+    const long long row = gid / (2LL * heads);
+    const int tok = (int)(row % rows_per_sample);
+    const float* w = tok < n_first ? (which ? wk : wq) : (which ? wk2 : wq2);
+    float* p = qk + (size_t)row * (2 * heads * dh) + (size_t)which * heads * dh + (size_t)head * dh;
+    float ss = 0.f;
+    for (int i = 0; i < dh; ++i) ss = fmaf(p[i], p[i], ss);
+    const float r = 1.0f / sqrtf(ss / (float)dh + eps);
+    for (int i = 0; i < dh; ++i) p[i] = p[i] * r * w[i];
+}
+
+int launch_qk_rmsnorm(void* qk, int dt, long long rows, int rows_per_sample, int n_first, int heads, int dh, const float* wq, const float* wk,
+                      const float* wq2, const float* wk2, float eps, hipStream_t s) {
+    if (dh > 64 || dh % 8 || !wq || !wk) return 1;
+    if (!wq2) wq2 = wq;
+    if (!wk2) wk2 = wk;
+    const long long total = rows * heads * 2;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dt == DT_F32) hipLaunchKernelGGL(qk_rmsnorm_f32_kernel, grid, dim3(256), 0, s, reinterpret_cast<float*>(qk), rows, rows_per_sample, n_first, heads, dh, wq, wk, wq2, wk2, eps);
+    else if (dt == DT_F16) hipLaunchKernelGGL(qk_rmsnorm_kernel<DT_F16>, grid, dim3(256), 0, s, qk, rows, rows_per_sample, n_first, heads, dh, wq, wk, wq2, wk2, eps);
+    else hipLaunchKernelGGL(qk_rmsnorm_kernel<DT_BF16>, grid, dim3(256), 0, s, qk, rows, rows_per_sample, n_first, heads, dh, wq, wk, wq2, wk2, eps);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}

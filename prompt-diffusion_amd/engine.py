@@ -148,7 +148,7 @@ EXPORTS = [
     "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_set_guidance", "pd_sample_eps_at", "pd_sample_end",
     "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_wait_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_encode_ex", "pd_text_weights_missing",
     "pd_profile_read", "pd_profile_dump",
-    "pd_sd3_configure", "pd_sd3_weights_missing", "pd_sd3_forward", "pd_sd3_control", "pd_sd3_sample",
+    "pd_sd3_configure", "pd_sd3_weights_missing", "pd_sd3_forward", "pd_sd3_control", "pd_sd3_sample", "pd_sd3_down_proj",
     "pd_op_conv2d", "pd_op_linear", "pd_op_linear_fp8", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention", "pd_op_spatial_transformer",
 ]
 

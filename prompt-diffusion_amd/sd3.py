@@ -31,10 +31,11 @@ class SD3Config:
     pos_embed_max_size: int = 192
     cn_pos_embed_max_size: int = 0  # 0: same as the transformer's
     force_zeros_for_pooled_projection: bool = True   # the reference class's default (promptdiffusioncontrolnet_sd3.py:108)
-    # constructor arguments of the reference class this engine does not implement (promptdiffusioncontrolnet_sd3.py:104-105):
-    # anything but the defaults is rejected, so an SD3.5-style checkpoint cannot load as a silently different network
-    qk_norm: Optional[str] = None
-    dual_attention_layers: tuple = ()
+    # SD3.5-style blocks (promptdiffusioncontrolnet_sd3.py:104-105, :140-141): per-head RMSNorm of queries / keys, and a second,
+    # image-only attention in the listed blocks (own lists for the transformer and the ControlNet)
+    qk_norm: Optional[str] = None            # None or "rms_norm"
+    dual_attention_layers: tuple = ()        # transformer blocks with attn2
+    cn_dual_attention_layers: tuple = ()     # ControlNet blocks with attn2 (the reference class's dual_attention_layers)
 
     @property
     def hidden(self) -> int:
@@ -50,7 +51,7 @@ class pd_sd3_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_channels", "out_channels", "patch_size", "heads", "head_dim", "layers", "cn_layers",
                                          "joint_dim", "pooled_dim", "pos_embed_max_size", "cn_pos_embed_max_size",
                                          "cn_zero_pooled")] + \
-               [("reserved", C.c_int32 * 4)]
+               [("qk_norm", C.c_int32), ("dual_mask", C.c_uint32), ("cn_dual_mask", C.c_uint32), ("reserved", C.c_int32 * 1)]
 
 
 class pd_sd3_args(C.Structure):
@@ -96,6 +97,7 @@ def sd3_param_shapes(cfg: SD3Config) -> Dict[str, tuple]:
         if cn:
             out[net + "pos_embed_input.proj.weight"] = (D, cfg.in_channels, cfg.patch, cfg.patch)
             out[net + "pos_embed_input.proj.bias"] = (D,)
+            out[net + "down_proj.weight"], out[net + "down_proj.bias"] = (3, 6, 3, 3), (3,)      # promptdiffusioncontrolnet_sd3.py:114
         lin(net + "time_text_embed.timestep_embedder.linear_1", D, 256)
         lin(net + "time_text_embed.timestep_embedder.linear_2", D, D)
         lin(net + "time_text_embed.text_embedder.linear_1", D, cfg.pooled_dim)
@@ -104,10 +106,19 @@ def sd3_param_shapes(cfg: SD3Config) -> Dict[str, tuple]:
         for i in range(layers):
             b = f"{net}transformer_blocks.{i}."
             pre_only = (not cn) and i == layers - 1
-            lin(b + "norm1.linear", 6 * D, D)
+            dual = i in tuple(cfg.cn_dual_attention_layers if cn else cfg.dual_attention_layers)
+            lin(b + "norm1.linear", (9 if dual else 6) * D, D)
             lin(b + "norm1_context.linear", (2 if pre_only else 6) * D, D)
             for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0"):
                 lin(b + "attn." + n, D, D)
+            if cfg.qk_norm:
+                for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                    out[b + "attn." + n + ".weight"] = (cfg.head_dim,)
+            if dual:
+                for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                    lin(b + "attn2." + n, D, D)
+                if cfg.qk_norm:
+                    out[b + "attn2.norm_q.weight"], out[b + "attn2.norm_k.weight"] = (cfg.head_dim,), (cfg.head_dim,)
             lin(b + "ff.net.0.proj", 4 * D, D)
             lin(b + "ff.net.2", D, 4 * D)
             if not pre_only:
@@ -133,6 +144,8 @@ def synth_sd3_state_dict(cfg: SD3Config, seed: int = 0) -> Dict[str, np.ndarray]
             sd[name] = sincos_pos_embed(shp[2], m, base_size=max(1, m // 2))[None].astype(np.float32)
         elif name.endswith(".bias"):
             sd[name] = (0.05 * rng.standard_normal(shp)).astype(np.float32)
+        elif len(shp) == 1:                                   # RMSNorm weights of qk_norm
+            sd[name] = (1.0 + 0.1 * rng.standard_normal(shp)).astype(np.float32)
         else:
             fan_in = int(np.prod(shp[1:]))
             scale = 0.5 if "norm1" in name or "norm_out" in name else 1.0     # keep the modulation gates moderate
@@ -150,9 +163,13 @@ class SD3Engine:
         the block-scaled K = 128 MFMA (twice the f16 rate); level 2 (= True) also the feed-forward-out projections, whose
         input (the GELU output) is stored as e4m3 under a norm bound.  fp8=1: the first group only.  Everything else stays
         in `precision`."""
-        if cfg.qk_norm is not None or tuple(cfg.dual_attention_layers):
-            raise NotImplementedError("qk_norm / dual_attention_layers (SD3.5 blocks, promptdiffusioncontrolnet_sd3.py:104-105, "
-                                      ":140-141) are not built: this engine implements the SD3-medium JointTransformerBlock only")
+        if cfg.qk_norm not in (None, "rms_norm"):
+            raise NotImplementedError(f"qk_norm={cfg.qk_norm!r}: only None and 'rms_norm' are built (promptdiffusioncontrolnet_sd3.py:105)")
+        for lst, n in ((cfg.dual_attention_layers, cfg.layers), (cfg.cn_dual_attention_layers, cfg.cn_layers)):
+            if any(i < 0 or i >= min(n, 32) for i in lst):
+                raise ValueError("dual_attention_layers index out of range")
+        if cfg.layers - 1 in tuple(cfg.dual_attention_layers):
+            raise NotImplementedError("the context_pre_only last block cannot carry a second attention")
         self.cfg = cfg
         self.base = E.Engine(W.TINY, device=device, precision=precision, stream_f32=stream_f32, lib_path=lib_path)
         lib = self.base.lib
@@ -161,9 +178,11 @@ class SD3Engine:
         lib.pd_sd3_forward.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_void_p]
         lib.pd_sd3_control.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_int32, C.c_void_p]
         lib.pd_sd3_sample.argtypes = [C.c_void_p, C.POINTER(pd_sd3_args), C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+        lib.pd_sd3_down_proj.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         c = pd_sd3_config(cfg.in_channels, cfg.out_channels, cfg.patch, cfg.heads, cfg.head_dim, cfg.layers, cfg.cn_layers,
                           cfg.joint_dim, cfg.pooled_dim, cfg.pos_embed_max_size, cfg.cn_pos_embed_max_size,
-                          1 if cfg.force_zeros_for_pooled_projection else 0)
+                          1 if cfg.force_zeros_for_pooled_projection else 0, 1 if cfg.qk_norm else 0,
+                          sum(1 << i for i in cfg.dual_attention_layers), sum(1 << i for i in cfg.cn_dual_attention_layers))
         self.base._check(lib.pd_sd3_configure(self.base._h, C.byref(c)))
         self.fp8 = 2 if fp8 is True else int(fp8)
         if self.fp8:
@@ -193,6 +212,28 @@ class SD3Engine:
 
     def init_random_weights(self, seed: int = 1234) -> None:
         self.base.init_random_weights(seed)
+
+    def encode_support_pair(self, cond, gt, vae=None):
+        """SD3PromptDiffusionModel.encode_support_pair (promptdiffusioncontrolnet_sd3.py:189-198): down_proj (Conv2d 6 -> 3, 3x3)
+        over cat([cond, gt], 1) on the engine; with a `vae` the caller's encoder turns the result into latents
+        (``vae.encode(x).latent_dist.sample()``), as the reference does."""
+        b0, b1 = E._Buf(cond), E._Buf(gt)
+        if b0.mem != b1.mem or tuple(b0.owner.shape) != tuple(b1.owner.shape) or b0.owner.shape[1] != 3:
+            raise ValueError("cond and gt must be [B, 3, H, W] in the same memory space")
+        Bn, _, H, Wd = b0.owner.shape
+        if b0.mem == E.PD_MEM_DEVICE:
+            import torch
+            pair = torch.cat([b0.owner, b1.owner], 1).contiguous()
+            out = torch.empty((Bn, 3, H, Wd), dtype=torch.float32, device=pair.device)
+            self.base._order_after_torch(b0.mem)
+            self.base._check(self.base.lib.pd_sd3_down_proj(self.base._h, pair.data_ptr(), Bn, H, Wd, b0.mem, out.data_ptr()))
+        else:
+            pair = np.ascontiguousarray(np.concatenate([b0.owner, b1.owner], 1), np.float32)
+            out = np.empty((Bn, 3, H, Wd), np.float32)
+            self.base._check(self.base.lib.pd_sd3_down_proj(self.base._h, pair.ctypes.data, Bn, H, Wd, b0.mem, out.ctypes.data))
+        if vae is not None:
+            return vae.encode(out).latent_dist.sample()
+        return out
 
     def weights_missing(self) -> int:
         return int(self.base.lib.pd_sd3_weights_missing(self.base._h))

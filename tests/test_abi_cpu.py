@@ -59,11 +59,23 @@ def test_product_does_not_import_oracle():
 
 
 def test_sd3_rejects_unbuilt_block_variants():
-    """promptdiffusioncontrolnet_sd3.py:104-105: qk_norm / dual_attention_layers select blocks this engine does not build;
-    they must be refused before any engine exists instead of loading as a different network."""
+    """promptdiffusioncontrolnet_sd3.py:104-105: qk_norm other than rms_norm, or a second attention in the context_pre_only last
+    block, select blocks this engine does not build; they must be refused before any engine exists."""
     import pytest
     from prompt_diffusion_amd import sd3
     import dataclasses
-    for kw in ({"qk_norm": "rms_norm"}, {"dual_attention_layers": (0, 1)}):
-        with pytest.raises(NotImplementedError):
-            sd3.SD3Engine(dataclasses.replace(sd3.SD3_TINY, **kw))
+    with pytest.raises(NotImplementedError):
+        sd3.SD3Engine(dataclasses.replace(sd3.SD3_TINY, qk_norm="layer_norm"))
+    with pytest.raises(NotImplementedError):
+        sd3.SD3Engine(dataclasses.replace(sd3.SD3_TINY, dual_attention_layers=(sd3.SD3_TINY.layers - 1,)))
+    with pytest.raises(ValueError):
+        sd3.SD3Engine(dataclasses.replace(sd3.SD3_TINY, cn_dual_attention_layers=(7,)))
+    # the SD3.5-style parameter inventory: RMSNorm weights per attention, attn2.* and 9 modulation chunks in the dual blocks
+    cfg = dataclasses.replace(sd3.SD3_TINY, qk_norm="rms_norm", dual_attention_layers=(0,), cn_dual_attention_layers=(1,))
+    sh = sd3.sd3_param_shapes(cfg)
+    D = cfg.hidden
+    assert sh["transformer.transformer_blocks.0.norm1.linear.weight"] == (9 * D, D)
+    assert sh["transformer.transformer_blocks.1.norm1.linear.weight"] == (6 * D, D)
+    assert sh["controlnet.transformer_blocks.1.attn2.to_out.0.weight"] == (D, D)
+    assert sh["transformer.transformer_blocks.2.attn.norm_added_k.weight"] == (cfg.head_dim,)
+    assert sh["controlnet.down_proj.weight"] == (3, 6, 3, 3)

@@ -219,3 +219,77 @@ def test_fp8_option_against_emulating_oracle(sd, prec, level):
     with pytest.raises(ValueError):
         sd3.SD3Engine(CFG, precision="f32", fp8=True)
     e.close()
+
+
+@pytest.mark.parametrize("prec", ["f16x2", "f16"])
+def test_mid_size_against_oracle(prec):
+    """Oracle-vs-HIP beyond the toy widths: width 512 (8 heads x 64), 8 transformer + 3 ControlNet blocks, 16 latent channels,
+    32 x 32 latents -> 256 image + 77 context tokens -- the largest configuration the NumPy oracle finishes in seconds.  It
+    exercises the 256-row GEMM tiles, multi-tile attention over the joint 333-token sequence and the two-stream schedule that
+    SD3-medium runs through, which the two-block toy config does not."""
+    import dataclasses
+    cfg = dataclasses.replace(sd3.SD3_MEDIUM, heads=8, head_dim=64, layers=8, cn_layers=3, joint_dim=512, pooled_dim=256,
+                              pos_embed_max_size=32)
+    w = sd3.synth_sd3_state_dict(cfg, seed=21)
+    i = inputs(2, 32, 32, 77, seed=22, cfg=cfg)
+    ctl = O.controlnet_forward(w, cfg, i["x"], i["t"], i["ctx"], np.zeros_like(i["pooled"]), i["cond"], i["pair"], 1.0)
+    ref = O.transformer_forward(w, cfg, i["x"], i["t"], i["ctx"], i["pooled"], ctl)
+    e = sd3.SD3Engine(cfg, precision=prec)
+    e.load_state_dict(w)
+    got = e.forward(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 1.0)
+    got_ctl = e.controlnet(i["x"], i["t"], i["ctx"], np.zeros_like(i["pooled"]), i["cond"], i["pair"], 1.0)
+    e.close()
+    tol = {"f16x2": 3e-4, "f16": 1.5e-2}[prec]
+    for g, r in zip(got_ctl, ctl):
+        assert relerr(g, r) < tol
+    print("SD3 mid-size %s vs oracle: %.2e" % (prec, relerr(got, ref)))
+    assert relerr(got, ref) < tol
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_sd35_style_blocks(prec):
+    """qk_norm = "rms_norm" (per-head RMSNorm of queries and keys, own weights for the image and the context stream) and
+    dual_attention_layers (attn2: a second, image-only attention on the 7th-9th modulation chunks) in both networks
+    (promptdiffusioncontrolnet_sd3.py:104-105, :140-141), against the oracle's restatement."""
+    import dataclasses
+    cfg = dataclasses.replace(CFG, qk_norm="rms_norm", dual_attention_layers=(0, 1), cn_dual_attention_layers=(1,))
+    w = sd3.synth_sd3_state_dict(cfg, seed=3)
+    e = sd3.SD3Engine(cfg, precision=prec)
+    e.load_state_dict(w)
+    for B, H, Wd, S in ((2, 8, 12, 5), (1, 6, 4, 77)):     # the second one: 6 image tokens, V^T padded to 8
+        i = inputs(B, H, Wd, S, seed=40 + B, cfg=cfg)
+        ctl = O.controlnet_forward(w, cfg, i["x"], i["t"], i["ctx"], np.zeros_like(i["pooled"]), i["cond"], i["pair"], 0.9)
+        ref = O.transformer_forward(w, cfg, i["x"], i["t"], i["ctx"], i["pooled"], ctl)
+        got = e.forward(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 0.9)
+        assert relerr(got, ref) < TOL[prec], (B, relerr(got, ref))
+        plain_cfg = dataclasses.replace(cfg, qk_norm=None)
+        # the same weights without the RMSNorm give a different velocity: the norm is really applied
+        ref_plain = O.transformer_forward(w, plain_cfg, i["x"], i["t"], i["ctx"], i["pooled"], None)
+        ref_norm = O.transformer_forward(w, cfg, i["x"], i["t"], i["ctx"], i["pooled"], None)
+        assert relerr(ref_plain, ref_norm) > 1e-2
+    e.close()
+
+
+def test_down_proj_and_strict_loading():
+    """encode_support_pair's Conv2d(6, 3, 3, padding=1) on the engine (promptdiffusioncontrolnet_sd3.py:114, :189-198); strict
+    loading refuses tensors of blocks the configuration does not have."""
+    w = sd3.synth_sd3_state_dict(CFG, seed=5)
+    e = sd3.SD3Engine(CFG, precision="f32")
+    e.load_state_dict(w)
+    rng = np.random.default_rng(6)
+    cond, gt = rng.standard_normal((2, 3, 20, 12)).astype(np.float32), rng.standard_normal((2, 3, 20, 12)).astype(np.float32)
+    got = e.encode_support_pair(cond, gt)
+    ref = O.down_proj(w, np.concatenate([cond, gt], 1))
+    assert got.shape == ref.shape and relerr(got, ref) < 2e-5
+
+    class _Dist:
+        def __init__(self, x): self.x = x
+        def sample(self): return self.x[:, :, ::8, ::8] * 2.0
+    class _Vae:
+        def encode(self, x): return type("o", (), {"latent_dist": _Dist(x)})()
+    assert np.array_equal(e.encode_support_pair(cond, gt, vae=_Vae()), got[:, :, ::8, ::8] * 2.0)
+    bad = dict(w)
+    bad["transformer.transformer_blocks.0.attn.norm_q.weight"] = np.ones(CFG.head_dim, np.float32)
+    with pytest.raises(E.PdError, match="unexpected"):
+        e.load_state_dict(bad)
+    e.close()
