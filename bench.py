@@ -321,15 +321,25 @@ def main():
             # HBM traffic per launch: PMC counters cannot be collected from inside this process; tools/final_measure.sh runs
             # the FETCH_SIZE / WRITE_SIZE passes on this same command line (50-step workload) and commits the summary
             traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(tpath):
+            prof_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            tpath = os.path.join(ROOT, "profiles", prof_files[-1]) if prof_files else ""
+            if tpath and os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f)
                 traffic = tj.get("igemm_kernel_hbm_bytes_per_launch")
-                traffic_source = "profiles/r02_pmc_traffic.json: " + tj.get("source", "")
+                traffic_source = "profiles/" + prof_files[-1] + ": " + tj.get("source", "")
+            # counter-backed MFMA-pipe utilisation per kernel family (tools/final_measure.sh, same 20-step workload)
+            mfma_util, util_source = None, None
+            util_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_mfma_util.json"))
+            if util_files:
+                with open(os.path.join(ROOT, "profiles", util_files[-1])) as f:
+                    uj = json.load(f)
+                mfma_util = {k: v.get("mfma_util") for k, v in uj.get("by_kernel", {}).items()}
+                util_source = "profiles/" + util_files[-1] + ": " + uj.get("definition", "")
             result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv / linear, all instantiations)",
                                   "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": traffic, "traffic_source": traffic_source,
+                                  "mfma_util": mfma_util, "mfma_util_source": util_source,
                                   "algorithmic_bytes_per_launch": alg_per_launch,
                                   "traffic_over_algorithmic": (traffic / alg_per_launch) if traffic else None,
                                   "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,

@@ -5,9 +5,11 @@ Per attention kernel: average duration (kernel trace), algorithmic TFLOP/s at th
 LDS cycles lost to bank conflicts), SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_WAVE_CYCLES."""
 import collections, csv, glob, json, sys
 
+import os
 stats_dir, pmc_dirs, out = sys.argv[1], sys.argv[2:-1], sys.argv[-1]
-FLOPS = 4.0 * 16 * 8 * 4096 * 4096 * 40
-res = {"shape": "B 16 x 8 heads, Nq = Nk = 4096, dh 40 (the 64x64-level self-attention of the headline workload)",
+NTOK = int(os.environ.get("ATTN_N", "4096"))
+FLOPS = 4.0 * 16 * 8 * NTOK * NTOK * 40
+res = {"shape": f"B 16 x 8 heads, Nq = Nk = {NTOK}, dh 40 (self-attention of the 64x64 level at 512x512: N 4096; at 768x768, BASELINE config #4: N 9216)",
        "algorithmic_flop_per_launch": FLOPS, "kernels": {}}
 for path in glob.glob(stats_dir + "/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(path)):
@@ -33,5 +35,11 @@ for name, k in res["kernels"].items():
         k["lds_bank_conflict_share"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
     if c.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
         k["mfma_busy_over_sq_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]
+    if c.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        # MFMA-pipe busy cycles over (1024 SIMDs x shader cycles of the dispatch); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        k["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+        k["clock_mhz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / k["avg_us"] if k.get("avg_us") else None
+        if c.get("SQ_INSTS_MFMA"):
+            k["valu_per_mfma"] = c.get("SQ_INSTS_VALU", 0.0) / c["SQ_INSTS_MFMA"]
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

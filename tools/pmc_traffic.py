@@ -5,7 +5,7 @@ counters are in KB.  usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> 
 import collections, csv, glob, json, sys
 
 FAMILIES = ("igemm_kernel<", "conv3x3_patch_kernel<", "conv3x3_patch2_kernel<", "attn2_kernel", "gn_apply_kernel<", "gn_stats_kernel<",
-            "gn_fused_kernel<", "layernorm_kernel<", "splitk_finalize_kernel", "concat_add_kernel")
+            "gn_fused_kernel<", "layernorm_kernel<", "splitk_finalize_kernel", "concat_add_kernel", "st_tail_kernel<", "st_front_kernel<")
 
 
 def collect(d, counter):
