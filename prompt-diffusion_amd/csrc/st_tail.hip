@@ -43,6 +43,9 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+#ifndef ST_NV
+#define ST_NV 0   // vector instructions placed behind each MFMA of the feed-forward's first product (x * gelu(gate) of the previous chunk)
+#endif
 constexpr int TC = 320;          // channels
 constexpr int TNT = 10;          // 32-channel tiles
 constexpr int TKS = 20;          // k16 steps over TC
@@ -91,8 +94,14 @@ template <int P, int S> __device__ __forceinline__ uint4 acc_frag(const f32x16& 
     u.z = pack2<P>(a[8 * S + 4], a[8 * S + 5]); u.w = pack2<P>(a[8 * S + 6], a[8 * S + 7]);
     return u;
 }
-__device__ __forceinline__ f32x16 lds_vec16(unsigned float_index) {   // 16 consecutive fp32 of the vector area
-    const f32x4* p = reinterpret_cast<const f32x4*>(smem + RING_BYTES) + (float_index >> 2);
+// 16 consecutive fp32 of the vector area: floats [index + 16 * (lane >> 5), +16).  The lane half comes out of lane16 (= lane * 16, live
+// in every step anyway) behind an opaque asm: a hoisted per-lane address would be one more register alive across the whole kernel, and
+// hipcc spilled exactly that one -- its reload put an `s_waitcnt vmcnt(0)` at the head of the feed-forward loop, which drained the
+// five steps of LDS-DMA prefetch in every iteration (85 cycles per MFMA there instead of 60).
+__device__ __forceinline__ f32x16 lds_vec16(unsigned float_index, unsigned lane16) {
+    unsigned l = lane16;
+    asm volatile("" : "+v"(l));
+    const f32x4* p = reinterpret_cast<const f32x4*>(smem + RING_BYTES + (l >> 9) * 64) + (float_index >> 2);
     const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
     return f32x16{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
 }
@@ -125,6 +134,9 @@ struct Pipe {
     unsigned lds0;      // LDS byte address of smem[0] (0 unless static LDS precedes the dynamic region)
     int wave;
     uint4 w0, w1, w2, w3;
+#ifdef PD_STAMP
+    unsigned long long t_vm = 0, t_bar = 0, t_dma = 0;   // cycles in the step's DMA wait, barrier and DMA issue (diagnostic build)
+#endif
     template <int I> __device__ __forceinline__ uint4& reg() {
         if constexpr (I == 0) return w0; else if constexpr (I == 1) return w1; else if constexpr (I == 2) return w2; else return w3;
     }
@@ -169,9 +181,22 @@ template <int NV = 0, class PIPE, class F> __device__ __forceinline__ void run_s
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         if constexpr (NV > 0) __builtin_amdgcn_sched_group_barrier(0x2, NV, 0);
         if constexpr (f == 9) {
+#ifdef PD_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long s0_ = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            const unsigned long long s1_ = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long s2_ = __builtin_amdgcn_s_memtime();
+            pp.issue(pp.st + PD);
+            const unsigned long long s3_ = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            pp.t_vm += s1_ - s0_; pp.t_bar += s2_ - s1_; pp.t_dma += s3_ - s2_;
+#else
             asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             pp.issue(pp.st + PD);
+#endif
         }
     });
     pp.advance();
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_BO1 + 32 * t + 16 * hh);
+    for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_BO1 + 32 * t, pp.lane16);
     pp.cur = pp.lane16;
     pp.nxt = STEP_BYTES + pp.lane16;
     pp.w0 = ldsr(pp.cur); pp.w1 = ldsr(pp.cur + 1024); pp.w2 = ldsr(pp.cur + 2048); pp.w3 = ldsr(pp.cur + 3072);
@@ -287,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
         uint4 qf[6];
         static_for<3>([&](auto TL) __attribute__((always_inline)) {
             constexpr int tl = decltype(TL)::value;
-            f32x16 qa = lds_vec16(V_BQ + 32 * (3 * pr + tl) + 16 * hh);
+            f32x16 qa = lds_vec16(V_BQ + 32 * (3 * pr + tl), pp.lane16);
             run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
                 mfma32<P>(w, yf[decltype(I)::value], qa);
                 return true;
@@ -386,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
         });
     }
 #pragma unroll
-    for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_BO2 + 32 * t + 16 * hh);
+    for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_BO2 + 32 * t, pp.lane16);
     PD_STAMP_AT(3);
 
     // ---- 6-8. GEGLU feed-forward in chunks of 32 hidden units, software-pipelined: while the matrix pipe runs ff.net.0 of chunk
@@ -394,11 +419,11 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
     // chunk c (2 k16 steps into each of the 10 output tiles)
     ln_frags<P>(acc, yf);   // norm3
 #pragma unroll
-    for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_B2 + 32 * t + 16 * hh);
+    for (int t = 0; t < TNT; ++t) acc[t] += lds_vec16(V_B2 + 32 * t, pp.lane16);
     f32x16 a1[2];
     static_for<2>([&](auto TI) __attribute__((always_inline)) {
         constexpr int ti = decltype(TI)::value;
-        a1[ti] = lds_vec16(V_B1 + ti * 32 + 16 * hh);
+        a1[ti] = lds_vec16(V_B1 + ti * 32, pp.lane16);
         run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
             mfma32<P>(w, yf[decltype(I)::value], a1[ti]);
             return true;
@@ -408,8 +433,8 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
         f32x16 a1n[2], g;
         static_for<2>([&](auto TI) __attribute__((always_inline)) {
             constexpr int ti = decltype(TI)::value;
-            a1n[ti] = lds_vec16(V_B1 + ((cc + 1) * 2 + ti) * 32 + 16 * hh);
-            run_step<0>(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
+            a1n[ti] = lds_vec16(V_B1 + ((cc + 1) * 2 + ti) * 32, pp.lane16);
+            run_step<ST_NV>(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
                 constexpr int o = ti * SF + decltype(I)::value;
                 mfma32<P>(w, yf[decltype(I)::value], a1n[ti]);
                 if constexpr (o % 5 == 0 || o % 5 == 2) {
@@ -448,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
         yf[2 * t + 1] = acc_frag<P, 1>(acc[t]);
     }
 #pragma unroll
-    for (int t = 0; t < TNT; ++t) acc[t] = load_row16<P, SF32>(a.x_in, (size_t)row * TC + 32 * t + 16 * hh) + lds_vec16(V_BP + 32 * t + 16 * hh);
+    for (int t = 0; t < TNT; ++t) acc[t] = load_row16<P, SF32>(a.x_in, (size_t)row * TC + 32 * t + 16 * hh) + lds_vec16(V_BP + 32 * t, pp.lane16);
     static_for<TNT>([&](auto TN) __attribute__((always_inline)) {
         constexpr int tn = decltype(TN)::value;
         run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
@@ -461,6 +486,9 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
 #pragma unroll
     for (int t = 0; t < TNT; ++t) store_row16<P, SF32>(a.out, (size_t)row * TC + 32 * t + 16 * hh, acc[t]);
     PD_STAMP_AT(6);
+#ifdef PD_STAMP
+    if (threadIdx.x == 0 && g_stamp_buf) { g_stamp_buf[(size_t)blockIdx.x * 16 + 8] = pp.t_vm; g_stamp_buf[(size_t)blockIdx.x * 16 + 9] = pp.t_bar; g_stamp_buf[(size_t)blockIdx.x * 16 + 10] = pp.t_dma; }
+#endif
 }
 
 
@@ -563,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontArgs a) {
     }
     f32x16 acc[TNT];
 #pragma unroll
-    for (int t = 0; t < TNT; ++t) acc[t] = lds_vec16(FV_BPI + 32 * t + 16 * hh);
+    for (int t = 0; t < TNT; ++t) acc[t] = lds_vec16(FV_BPI + 32 * t, pp.lane16);
     pp.cur = pp.lane16;
     pp.nxt = STEP_BYTES + pp.lane16;
     pp.w0 = ldsr(pp.cur); pp.w1 = ldsr(pp.cur + 1024); pp.w2 = ldsr(pp.cur + 2048); pp.w3 = ldsr(pp.cur + 3072);
@@ -595,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontArgs a) {
     uint16_t* qk0 = reinterpret_cast<uint16_t*>(a.qk) + (size_t)row0 * (2 * TC);
     uint16_t* vt0 = reinterpret_cast<uint16_t*>(a.vt) + (size_t)sample * TC * a.vt_ld + (row0 - sample * a.rows_per_sample);
     for (int tg = 0; tg < 30; tg += 2) {   // two tiles per trip keeps the loop body at 40 MFMAs
-        f32x16 o0 = lds_vec16(FV_BQKV + 32 * tg + 16 * hh), o1 = lds_vec16(FV_BQKV + 32 * (tg + 1) + 16 * hh);
+        f32x16 o0 = lds_vec16(FV_BQKV + 32 * tg, pp.lane16), o1 = lds_vec16(FV_BQKV + 32 * (tg + 1), pp.lane16);
         run_step(pp, [&](auto I, const uint4& w) __attribute__((always_inline)) {
             mfma32<P>(w, yf[decltype(I)::value], o0);
             return true;

@@ -31,6 +31,13 @@ static void report(const char* name, unsigned long long* dstamps, int blocks, in
     std::vector<unsigned long long> st;
     for (int b = 0; b < blocks; ++b) st.push_back(h[(size_t)b * 16]);
     std::sort(st.begin(), st.end());
+    {
+        std::vector<double> a, b, c;
+        for (int bk = 0; bk < blocks; ++bk) { a.push_back((double)h[(size_t)bk * 16 + 8]); b.push_back((double)h[(size_t)bk * 16 + 9]); c.push_back((double)h[(size_t)bk * 16 + 10]); }
+        std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); std::sort(c.begin(), c.end());
+        if (c[c.size() / 2] > 0)
+            printf("  of which, summed over the ring steps: DMA wait (vmcnt) %.0f, barrier %.0f, DMA issue %.0f cycles\n", a[a.size() / 2], b[b.size() / 2], c[c.size() / 2]);
+    }
     printf("  total %.0f cycles per workgroup; start stamps span %.0f cycles (first to last workgroup; 2 rounds of 256)\n", total, (double)(st.back() - st.front()));
 }
 
