@@ -245,7 +245,8 @@ int pd_bench_linear(pd_engine* e, int32_t M, int32_t K, int32_t N, int32_t resid
  * Parameter names are diffusers' state-dict names under the prefixes "transformer." (SD3Transformer2DModel) and
  * "controlnet." (SD3PromptDiffusionModel).  The example-pair / query conditions arrive as VAE latents: pd_sd3_down_proj is the
  * Conv2d(6, 3) half of encode_support_pair (promptdiffusioncontrolnet_sd3.py:189-198); vae.encode stays with the caller.
- * Not built: the SD3SingleTransformerBlock branch (joint_attention_dim = None, :147-160), joint_attention_kwargs / LoRA scale. */
+ * Not built: use_pos_embed = False (the ControlNet fed pre-embedded tokens, which the reference's own pipeline never does),
+ * joint_attention_kwargs / LoRA scale. */
 typedef struct pd_sd3_config {
     int32_t in_channels;        /* 16 */
     int32_t out_channels;       /* 16 */
@@ -265,7 +266,8 @@ typedef struct pd_sd3_config {
     uint32_t dual_mask;         /* bit i: transformer block i carries attn2, a second attention over the image tokens alone
                                    (dual_attention_layers, :104,141; norm1.linear then has 9 chunks) */
     uint32_t cn_dual_mask;      /* the same for the ControlNet's blocks */
-    int32_t reserved[1];
+    int32_t cn_single;          /* 1: the ControlNet consists of SD3SingleTransformerBlocks (joint_attention_dim = None, :147-160): no
+                                   context_embedder, no context stream; its blocks see the image tokens alone */
 } pd_sd3_config;
 
 typedef struct pd_sd3_args {

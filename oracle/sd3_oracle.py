@@ -194,6 +194,23 @@ def joint_block(sd, pre, cfg, x, c, temb, context_pre_only, fp8=False, dual=Fals
     return c, x
 
 
+def single_block(sd, pre, cfg, x, temb):
+    """SD3SingleTransformerBlock (the ControlNet's blocks when joint_attention_dim is None, promptdiffusioncontrolnet_sd3.py:147-160):
+    the image half of the joint block -- AdaLN-Zero, self-attention over the image tokens, gated residual, LayerNorm + tanh-GELU MLP."""
+    P = lambda n: sd[pre + n]
+    e = silu(temb)
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = np.split(linear(e, P("norm1.linear.weight"), P("norm1.linear.bias")), 6, axis=-1)
+    xn = layer_norm_noaffine(x) * (1 + sc_a[:, None]) + sh_a[:, None]
+    q, k = linear(xn, P("attn.to_q.weight"), P("attn.to_q.bias")), linear(xn, P("attn.to_k.weight"), P("attn.to_k.bias"))
+    if getattr(cfg, "qk_norm", None) == "rms_norm":
+        q, k = rms_norm_heads(q, P("attn.norm_q.weight"), cfg.heads), rms_norm_heads(k, P("attn.norm_k.weight"), cfg.heads)
+    o = attention(q, k, linear(xn, P("attn.to_v.weight"), P("attn.to_v.bias")), cfg.heads)
+    x = x + g_a[:, None] * linear(o, P("attn.to_out.0.weight"), P("attn.to_out.0.bias"))
+    xn2 = layer_norm_noaffine(x) * (1 + sc_m[:, None]) + sh_m[:, None]
+    ff = linear(gelu_tanh(linear(xn2, P("ff.net.0.proj.weight"), P("ff.net.0.proj.bias"))), P("ff.net.2.weight"), P("ff.net.2.bias"))
+    return (x + g_m[:, None] * ff).astype(F32)
+
+
 def time_text_embed(sd, pre, t, pooled):
     """CombinedTimestepTextProjEmbeddings: MLP(sinusoid(t)) + MLP(pooled)."""
     P = lambda n: sd[pre + n]
@@ -212,13 +229,17 @@ def controlnet_forward(sd, cfg, x, t, ctx, pooled, cond, pair, scale=1.0, prefix
     hs = patch_embed(x, P("pos_embed.proj.weight"), P("pos_embed.proj.bias"), cfg.patch)
     hs = hs + cropped_pos_embed(P("pos_embed.pos_embed")[0], cfg.cn_pos_embed_max_size or cfg.pos_embed_max_size, h, w)[None]
     temb = time_text_embed(sd, prefix + "time_text_embed.", t, pooled)
-    c = linear(ctx, P("context_embedder.weight"), P("context_embedder.bias"))
+    single = bool(getattr(cfg, "cn_single_blocks", False))      # joint_attention_dim=None: no context stream at all (:147-160, :426-431)
+    c = None if single else linear(ctx, P("context_embedder.weight"), P("context_embedder.bias"))
     pi_w, pi_b = P("pos_embed_input.proj.weight"), P("pos_embed_input.proj.bias")
     hs = (hs + patch_embed(cond, pi_w, pi_b, cfg.patch) + patch_embed(pair, pi_w, pi_b, cfg.patch)).astype(F32)   # :440
     res = []
     for i in range(cfg.cn_layers):
-        c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, False, fp8,
-                            dual=i in tuple(getattr(cfg, "cn_dual_attention_layers", ())))
+        if single:
+            hs = single_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, temb)
+        else:
+            c, hs = joint_block(sd, f"{prefix}transformer_blocks.{i}.", cfg, hs, c, temb, False, fp8,
+                                dual=i in tuple(getattr(cfg, "cn_dual_attention_layers", ())))
         res.append(hs)
     return [(linear(r, P(f"controlnet_blocks.{i}.weight"), P(f"controlnet_blocks.{i}.bias")) * F32(scale)).astype(F32)
             for i, r in enumerate(res)]

@@ -157,6 +157,7 @@ struct Sd3BlockW {
     WMat ff1, ff2, ffc1, ffc2;
     int mod_off = 0, mod_c_off = 0;   // first row of norm1.linear / norm1_context.linear in the net's modulation matrix
     bool pre_only = false;            // context_pre_only (last transformer block): context gives keys / values only
+    bool single = false;              // SD3SingleTransformerBlock: no context stream at all (ControlNet with joint_attention_dim = None)
     // qk_norm = "rms_norm": RMSNorm weights [head_dim] of the image / context queries and keys
     float *nq = nullptr, *nk = nullptr, *naq = nullptr, *nak = nullptr;
     // dual_attention_layers: attn2, self-attention over the image tokens (norm1.linear has 9 chunks: shift2 / scale2 / gate2 last)
@@ -165,7 +166,7 @@ struct Sd3BlockW {
     float *nq2 = nullptr, *nk2 = nullptr;
 };
 struct Sd3NetW {
-    bool built = false;
+    bool built = false, single = false;
     int layers = 0, pos_max = 0;
     WMat pe, pe_in, t1, t2, p1, p2, ctx_emb, mod, proj_out;
     ConvW down_proj;                  // ControlNet only: Conv2d(6, 3, 3, padding 1) of encode_support_pair

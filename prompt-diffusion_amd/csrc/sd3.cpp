@@ -47,16 +47,19 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
     lin(net.t2, "time_text_embed.timestep_embedder.linear_2", D, D);
     lin(net.p1, "time_text_embed.text_embedder.linear_1", D, sd3.pooled_dim);
     lin(net.p2, "time_text_embed.text_embedder.linear_2", D, D);
-    lin(net.ctx_emb, "context_embedder", D, sd3.joint_dim);
+    // joint_attention_dim = None (promptdiffusioncontrolnet_sd3.py:147-160): SD3SingleTransformerBlocks, no context stream
+    net.single = controlnet && sd3.cn_single != 0;
+    if (!net.single) lin(net.ctx_emb, "context_embedder", D, sd3.joint_dim);
     // modulation matrix: every norm1.linear / norm1_context.linear (+ norm_out.linear) of the net stacked row-wise
     net.blocks.resize(net.layers);   // never resized again (Params point into it)
     int rows = 0;
     for (int i = 0; i < net.layers; ++i) {
         Sd3BlockW& b = net.blocks[i];
         b.pre_only = !controlnet && i == net.layers - 1;
-        b.dual = i < 32 && ((dual_mask >> i) & 1u) && !b.pre_only;
+        b.single = net.single;
+        b.dual = i < 32 && ((dual_mask >> i) & 1u) && !b.pre_only && !b.single;
         b.mod_off = rows; rows += (b.dual ? 9 : 6) * D;
-        b.mod_c_off = rows; rows += (b.pre_only ? 2 : 6) * D;
+        b.mod_c_off = rows; rows += b.single ? 0 : (b.pre_only ? 2 : 6) * D;
     }
     if (!controlnet) { net.norm_out_off = rows; rows += 2 * D; }
     net.mod_rows = rows;
@@ -67,15 +70,18 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
         reg_mat(Bp + "norm1.linear.weight", {(b.dual ? 9 : 6) * D, D}, &net.mod, b.mod_off, false);
         reg_bias(Bp + "norm1.linear.bias", &net.mod, b.mod_off, (b.dual ? 9 : 6) * D);
         const int nc = (b.pre_only ? 2 : 6) * D;
-        reg_mat(Bp + "norm1_context.linear.weight", {nc, D}, &net.mod, b.mod_c_off, false);
-        reg_bias(Bp + "norm1_context.linear.bias", &net.mod, b.mod_c_off, nc);
+        if (!b.single) {
+            reg_mat(Bp + "norm1_context.linear.weight", {nc, D}, &net.mod, b.mod_c_off, false);
+            reg_bias(Bp + "norm1_context.linear.bias", &net.mod, b.mod_c_off, nc);
+        }
         make_mat(b.qkv, 3 * D, D, 1, D, true);
-        make_mat(b.qkv_c, 3 * D, D, 1, D, true);
+        if (!b.single) make_mat(b.qkv_c, 3 * D, D, 1, D, true);
         const char* nm[3] = {"to_q", "to_k", "to_v"};
         const char* nmc[3] = {"add_q_proj", "add_k_proj", "add_v_proj"};
         for (int j = 0; j < 3; ++j) {
             reg_mat(Bp + "attn." + nm[j] + ".weight", {D, D}, &b.qkv, j * D, false);
             reg_bias(Bp + "attn." + nm[j] + ".bias", &b.qkv, j * D, D);
+            if (b.single) continue;
             reg_mat(Bp + "attn." + nmc[j] + ".weight", {D, D}, &b.qkv_c, j * D, false);
             reg_bias(Bp + "attn." + nmc[j] + ".bias", &b.qkv_c, j * D, D);
         }
@@ -83,8 +89,10 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
         if (sd3.qk_norm) {
             reg_vec(Bp + "attn.norm_q.weight", hd, &b.nq, 'g');
             reg_vec(Bp + "attn.norm_k.weight", hd, &b.nk, 'g');
-            reg_vec(Bp + "attn.norm_added_q.weight", hd, &b.naq, 'g');
-            reg_vec(Bp + "attn.norm_added_k.weight", hd, &b.nak, 'g');
+            if (!b.single) {
+                reg_vec(Bp + "attn.norm_added_q.weight", hd, &b.naq, 'g');
+                reg_vec(Bp + "attn.norm_added_k.weight", hd, &b.nak, 'g');
+            }
         }
         if (b.dual) {
             make_mat(b.qkv2, 3 * D, D, 1, D, true);
@@ -100,7 +108,7 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
         }
         lin(b.ff1, "transformer_blocks." + std::to_string(i) + ".ff.net.0.proj", 4 * D, D);
         lin(b.ff2, "transformer_blocks." + std::to_string(i) + ".ff.net.2", D, 4 * D);
-        if (!b.pre_only) {
+        if (!b.pre_only && !b.single) {
             lin(b.out_c, "transformer_blocks." + std::to_string(i) + ".attn.to_add_out", D, D);
             lin(b.ffc1, "transformer_blocks." + std::to_string(i) + ".ff_context.net.0.proj", 4 * D, D);
             lin(b.ffc2, "transformer_blocks." + std::to_string(i) + ".ff_context.net.2", D, 4 * D);
@@ -121,7 +129,7 @@ void pd_engine::build_sd3_net(const std::string& P, Sd3NetW& net, bool controlne
 int pd_engine::sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs, Act& c, Act& modbuf) {
     const int D = sd3.heads * sd3.head_dim, ps = sd3.patch_size, h = io.H / ps, w = io.W / ps, N = h * w, B = io.B;
     hs = new_act(B, N, 1, D, S);
-    c = new_act(B, io.S, 1, D, S);
+    c = new_act(B, net.single ? 0 : io.S, 1, D, S);   // a single-block net has no context stream
     modbuf = new_act(B, 1, 1, net.mod_rows, DT_F32);
     const size_t mk = arena.mark();
     WMat pe = net.pe;            // the GEMM sees the patch conv as a linear layer over the patchified rows
@@ -176,6 +184,7 @@ int pd_engine::sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs
     // every AdaLN modulation of the net: Linear(SiLU(temb)) stacked
     PD_TRY(gemm(net.mod, temb, modbuf, 1, 0, 0, 1.f, nullptr, nullptr, 0, /*a_silu=*/true, nullptr, 0, 0));
     // context_embedder
+    if (net.single) { arena.release(mk); return 0; }
     Act ctx = new_act(B, io.S, 1, round_up(sd3.joint_dim, 8), T);
     if (!arena.dry) {
         ++launches;
@@ -194,7 +203,8 @@ int pd_engine::sd3_embed(Sd3NetW& net, const Sd3Io& io, bool controlnet, Act& hs
 // the same pair serves every block of a network, so the pad is cleared once per evaluation).
 // pre_add: x += *pre_add before anything else (folded into the first AdaLN pass).
 int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt, const Act* pre_add) {
-    const int D = x.C, B = x.B, N = x.H, Sx = c.H, Nt = N + Sx, heads = sd3.heads;
+    const int D = x.C, B = x.B, N = x.H, Sx = b.single ? 0 : c.H, Nt = N + Sx, heads = sd3.heads;
+    const bool ctx_stream = !b.single;   // SD3SingleTransformerBlock: the image half alone
     const size_t eb = dt_size(T);
     const float* mod = reinterpret_cast<const float*>(modbuf.p);
     const int ms = modbuf.C, vt_ld = vt.C;
@@ -223,10 +233,11 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     };
     auto scales = [&](int rows) { return f8 ? reinterpret_cast<float*>(arena.alloc((size_t)rows * sizeof(float))) : nullptr; };
     Act xn = new_act(B, N, 1, D, NT), cn = new_act(B, Sx, 1, D, NT);
-    float *xs = scales(B * N), *cs = scales(B * Sx);
+    float *xs = scales(B * N), *cs = ctx_stream ? scales(B * Sx) : nullptr;
     if (pre_add && pre_add->dt != x.dt) { pd_set_error("internal: residual dtype mismatch"); return 1; }
     PD_TRY(adaln(x, xn, b.mod_off, b.mod_off + D, xs, pre_add ? pre_add->p : nullptr));   // (shift_msa, scale_msa, gate_msa, shift_mlp, ...)
-    if (b.pre_only) PD_TRY(adaln(c, cn, b.mod_c_off + D, b.mod_c_off, cs));     // AdaLayerNormContinuous: (scale, shift)
+    if (!ctx_stream) {}
+    else if (b.pre_only) PD_TRY(adaln(c, cn, b.mod_c_off + D, b.mod_c_off, cs));     // AdaLayerNormContinuous: (scale, shift)
     else PD_TRY(adaln(c, cn, b.mod_c_off, b.mod_c_off + D, cs));
     // dual_attention_layers: the second modulated copy of the block INPUT (chunks 6 / 7 of SD35AdaLayerNormZeroX) for attn2
     Act xn2;
@@ -248,9 +259,11 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
         Act o = qk; o.H = N;
         gx.c_sample_rows = Nt; gx.c_row_off = 0; gx.vt_tok_off = 0; gx.a_scale = xs;
         PD_TRY(gemm(b.qkv, xn, o, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * D, vt_ld));
-        o.H = Sx;
-        gx.c_sample_rows = Nt; gx.c_row_off = N; gx.vt_tok_off = N; gx.a_scale = cs;
-        PD_TRY(gemm(b.qkv_c, cn, o, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * D, vt_ld));
+        if (ctx_stream) {
+            o.H = Sx;
+            gx.c_sample_rows = Nt; gx.c_row_off = N; gx.vt_tok_off = N; gx.a_scale = cs;
+            PD_TRY(gemm(b.qkv_c, cn, o, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, vt.p, 2 * D, vt_ld));
+        }
     }
     PD_TRY(qk_norm(qk, Nt, N, b.nq, b.nk, b.naq, b.nak));   // per-head RMSNorm of q and k, own weights per stream
     // ONE attention launch over the joint sequence (image queries only in the context_pre_only block); the out-projections
@@ -262,7 +275,7 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
     PD_TRY(attention(qkp, 2 * D, qkp + (size_t)D * eb, 2 * D, vt.p, vt_ld, att.p, D, B, Nq, Nt, D, heads, false, bs, bs, (long long)Nt * D));
     gx.gate = mod + b.mod_off + 2 * D; gx.gate_stride = ms; gx.a_sample_rows = Nt; gx.a_row_off = 0;
     PD_TRY(gemm(b.out, att, x, 1, 0, 0, 1.f, &x, nullptr, 0, false, nullptr, 0, 0));       // x += gate_msa * to_out(o_x)
-    if (!b.pre_only) {
+    if (!b.pre_only && ctx_stream) {
         gx.gate = mod + b.mod_c_off + 2 * D; gx.gate_stride = ms; gx.a_sample_rows = Nt; gx.a_row_off = N;
         PD_TRY(gemm(b.out_c, att, c, 1, 0, 0, 1.f, &c, nullptr, 0, false, nullptr, 0, 0));
     }
@@ -291,7 +304,7 @@ int pd_engine::sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, 
         PD_TRY(gemm(b.ff2, f, x, 1, 0, 0, 1.f, &x, nullptr, 0, false, nullptr, 0, 0));
         arena.release(mk);
     }
-    if (!b.pre_only) {
+    if (!b.pre_only && ctx_stream) {
         Act n2 = new_act(B, Sx, 1, D, NT);
         float* ns = scales(B * Sx);
         float* fs = f8b ? scales(B * Sx) : nullptr;
@@ -316,8 +329,9 @@ int pd_engine::sd3_quantize() {
         if (!net->built) continue;
         for (Sd3BlockW& b : net->blocks) {
             const bool l2 = opt_sd3_fp8 >= 2;
-            WMat* mats[6] = {&b.qkv, &b.qkv_c, &b.ff1, b.pre_only ? nullptr : &b.ffc1, l2 ? &b.ff2 : nullptr,
-                             (l2 && !b.pre_only) ? &b.ffc2 : nullptr};
+            const bool cs = !b.pre_only && !b.single;   // the block has a context feed-forward
+            WMat* mats[6] = {&b.qkv, b.single ? nullptr : &b.qkv_c, &b.ff1, cs ? &b.ffc1 : nullptr, l2 ? &b.ff2 : nullptr,
+                             (l2 && cs) ? &b.ffc2 : nullptr};
             for (int i = 0; i < 6 && !r; ++i) {
                 WMat* m = mats[i];
                 if (!m) continue;
@@ -381,7 +395,7 @@ int pd_engine::sd3_forward(const Sd3Io& io, float* v_out, int control_index, flo
             Act hs, c, modbuf, qk, vt;
             PD_TRY(sd3_embed(net, io, true, hs, c, modbuf));
             {
-                const int Nt = N + io.S, vt_ld = round_up(Nt, 8);
+                const int Nt = N + (net.single ? 0 : io.S), vt_ld = round_up(Nt, 8);
                 qk = new_act(B, Nt, 1, 2 * D, T);
                 vt = new_act(B, D, 1, vt_ld, T);
                 if (!arena.dry && vt_ld != Nt) HIP_OK(hipMemsetAsync(vt.p, 0, vt.bytes(), stream));   // pad keys of V^T must read as 0
@@ -482,6 +496,10 @@ extern "C" int pd_sd3_configure(pd_engine* e, const pd_sd3_config* c) {
         return 1;
     }
     if (D % 8 || D > 2048) { pd_set_error("pd_sd3_configure: hidden size %lld must be a multiple of 8 and <= 2048", D); return 1; }
+    if ((c->cn_single != 0 && c->cn_single != 1) || (c->cn_single && c->cn_dual_mask)) {
+        pd_set_error("pd_sd3_configure: cn_single must be 0 or 1, and single blocks have no second attention (cn_dual_mask %u)", c->cn_dual_mask);
+        return 1;
+    }
     if (c->cn_layers > c->layers) { pd_set_error("pd_sd3_configure: more ControlNet blocks (%d) than transformer blocks (%d)", c->cn_layers, c->layers); return 1; }
     HIP_OK(hipSetDevice(e->device));
     e->sd3 = *c;

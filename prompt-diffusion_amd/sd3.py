@@ -36,6 +36,8 @@ class SD3Config:
     qk_norm: Optional[str] = None            # None or "rms_norm"
     dual_attention_layers: tuple = ()        # transformer blocks with attn2
     cn_dual_attention_layers: tuple = ()     # ControlNet blocks with attn2 (the reference class's dual_attention_layers)
+    cn_single_blocks: bool = False           # the ControlNet built with joint_attention_dim=None: SD3SingleTransformerBlock, no
+                                             # context stream / context_embedder (promptdiffusioncontrolnet_sd3.py:147-160)
 
     @property
     def hidden(self) -> int:
@@ -51,7 +53,7 @@ class pd_sd3_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_channels", "out_channels", "patch_size", "heads", "head_dim", "layers", "cn_layers",
                                          "joint_dim", "pooled_dim", "pos_embed_max_size", "cn_pos_embed_max_size",
                                          "cn_zero_pooled")] + \
-               [("qk_norm", C.c_int32), ("dual_mask", C.c_uint32), ("cn_dual_mask", C.c_uint32), ("reserved", C.c_int32 * 1)]
+               [("qk_norm", C.c_int32), ("dual_mask", C.c_uint32), ("cn_dual_mask", C.c_uint32), ("cn_single", C.c_int32)]
 
 
 class pd_sd3_args(C.Structure):
@@ -102,17 +104,20 @@ def sd3_param_shapes(cfg: SD3Config) -> Dict[str, tuple]:
         lin(net + "time_text_embed.timestep_embedder.linear_2", D, D)
         lin(net + "time_text_embed.text_embedder.linear_1", D, cfg.pooled_dim)
         lin(net + "time_text_embed.text_embedder.linear_2", D, D)
-        lin(net + "context_embedder", D, cfg.joint_dim)
+        single = cn and cfg.cn_single_blocks
+        if not single:
+            lin(net + "context_embedder", D, cfg.joint_dim)
         for i in range(layers):
             b = f"{net}transformer_blocks.{i}."
             pre_only = (not cn) and i == layers - 1
-            dual = i in tuple(cfg.cn_dual_attention_layers if cn else cfg.dual_attention_layers)
+            dual = (not single) and i in tuple(cfg.cn_dual_attention_layers if cn else cfg.dual_attention_layers)
             lin(b + "norm1.linear", (9 if dual else 6) * D, D)
-            lin(b + "norm1_context.linear", (2 if pre_only else 6) * D, D)
-            for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0"):
+            if not single:
+                lin(b + "norm1_context.linear", (2 if pre_only else 6) * D, D)
+            for n in ("to_q", "to_k", "to_v", "to_out.0") + (() if single else ("add_q_proj", "add_k_proj", "add_v_proj")):
                 lin(b + "attn." + n, D, D)
             if cfg.qk_norm:
-                for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                for n in ("norm_q", "norm_k") + (() if single else ("norm_added_q", "norm_added_k")):
                     out[b + "attn." + n + ".weight"] = (cfg.head_dim,)
             if dual:
                 for n in ("to_q", "to_k", "to_v", "to_out.0"):
@@ -121,7 +126,7 @@ def sd3_param_shapes(cfg: SD3Config) -> Dict[str, tuple]:
                     out[b + "attn2.norm_q.weight"], out[b + "attn2.norm_k.weight"] = (cfg.head_dim,), (cfg.head_dim,)
             lin(b + "ff.net.0.proj", 4 * D, D)
             lin(b + "ff.net.2", D, 4 * D)
-            if not pre_only:
+            if not pre_only and not single:
                 lin(b + "attn.to_add_out", D, D)
                 lin(b + "ff_context.net.0.proj", 4 * D, D)
                 lin(b + "ff_context.net.2", D, 4 * D)
@@ -168,6 +173,8 @@ class SD3Engine:
         for lst, n in ((cfg.dual_attention_layers, cfg.layers), (cfg.cn_dual_attention_layers, cfg.cn_layers)):
             if any(i < 0 or i >= min(n, 32) for i in lst):
                 raise ValueError("dual_attention_layers index out of range")
+        if cfg.cn_single_blocks and tuple(cfg.cn_dual_attention_layers):
+            raise ValueError("SD3SingleTransformerBlock has no second attention: cn_dual_attention_layers must be empty with cn_single_blocks")
         if cfg.layers - 1 in tuple(cfg.dual_attention_layers):
             raise NotImplementedError("the context_pre_only last block cannot carry a second attention")
         self.cfg = cfg
@@ -182,7 +189,8 @@ class SD3Engine:
         c = pd_sd3_config(cfg.in_channels, cfg.out_channels, cfg.patch, cfg.heads, cfg.head_dim, cfg.layers, cfg.cn_layers,
                           cfg.joint_dim, cfg.pooled_dim, cfg.pos_embed_max_size, cfg.cn_pos_embed_max_size,
                           1 if cfg.force_zeros_for_pooled_projection else 0, 1 if cfg.qk_norm else 0,
-                          sum(1 << i for i in cfg.dual_attention_layers), sum(1 << i for i in cfg.cn_dual_attention_layers))
+                          sum(1 << i for i in cfg.dual_attention_layers), sum(1 << i for i in cfg.cn_dual_attention_layers),
+                          1 if cfg.cn_single_blocks else 0)
         self.base._check(lib.pd_sd3_configure(self.base._h, C.byref(c)))
         self.fp8 = 2 if fp8 is True else int(fp8)
         if self.fp8:

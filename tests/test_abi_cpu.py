@@ -79,3 +79,10 @@ def test_sd3_rejects_unbuilt_block_variants():
     assert sh["controlnet.transformer_blocks.1.attn2.to_out.0.weight"] == (D, D)
     assert sh["transformer.transformer_blocks.2.attn.norm_added_k.weight"] == (cfg.head_dim,)
     assert sh["controlnet.down_proj.weight"] == (3, 6, 3, 3)
+    # joint_attention_dim = None for the ControlNet (:147-160): single blocks, no context parameters at all
+    with pytest.raises(ValueError):
+        sd3.SD3Engine(dataclasses.replace(sd3.SD3_TINY, cn_single_blocks=True, cn_dual_attention_layers=(0,)))
+    sh = sd3.sd3_param_shapes(dataclasses.replace(sd3.SD3_TINY, cn_single_blocks=True, qk_norm="rms_norm"))
+    cn = [k for k in sh if k.startswith("controlnet.")]
+    assert not any("context" in k or "add_" in k or "norm_added" in k for k in cn)
+    assert "controlnet.transformer_blocks.0.attn.norm_q.weight" in sh and "transformer.context_embedder.weight" in sh

@@ -270,6 +270,32 @@ def test_sd35_style_blocks(prec):
     e.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_single_block_controlnet(prec):
+    """The ControlNet built with joint_attention_dim = None (promptdiffusioncontrolnet_sd3.py:147-160, :426-431): its blocks are
+    SD3SingleTransformerBlocks that see the image tokens alone, it has no context_embedder, and the prompt does not reach it."""
+    import dataclasses
+    for cfg in (dataclasses.replace(CFG, cn_single_blocks=True), dataclasses.replace(CFG, cn_single_blocks=True, qk_norm="rms_norm")):
+        w = sd3.synth_sd3_state_dict(cfg, seed=8)
+        assert not any(k.startswith("controlnet.context_embedder") or "controlnet.transformer_blocks.0.ff_context" in k for k in w)
+        e = sd3.SD3Engine(cfg, precision=prec)
+        e.load_state_dict(w)
+        for B, H, Wd, S in ((2, 8, 12, 5), (1, 6, 4, 77)):
+            i = inputs(B, H, Wd, S, seed=60 + B, cfg=cfg)
+            zp = np.zeros_like(i["pooled"])
+            ctl = O.controlnet_forward(w, cfg, i["x"], i["t"], i["ctx"], zp, i["cond"], i["pair"], 0.8)
+            got_ctl = e.controlnet(i["x"], i["t"], i["ctx"], zp, i["cond"], i["pair"], 0.8)
+            for g, r in zip(got_ctl, ctl):
+                assert relerr(g, r) < TOL[prec]
+            # no context stream: another prompt gives the same residuals, bit for bit
+            other = e.controlnet(i["x"], i["t"], i["ctx"][:, ::-1].copy() * 3.0, zp, i["cond"], i["pair"], 0.8)
+            assert all(np.array_equal(a, b) for a, b in zip(got_ctl, other))
+            ref = O.transformer_forward(w, cfg, i["x"], i["t"], i["ctx"], i["pooled"], ctl)
+            got = e.forward(i["x"], i["t"], i["ctx"], i["pooled"], i["cond"], i["pair"], 0.8)
+            assert relerr(got, ref) < TOL[prec], (B, relerr(got, ref))
+        e.close()
+
+
 def test_down_proj_and_strict_loading():
     """encode_support_pair's Conv2d(6, 3, 3, padding=1) on the engine (promptdiffusioncontrolnet_sd3.py:114, :189-198); strict
     loading refuses tensors of blocks the configuration does not have."""
