@@ -290,6 +290,17 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
 
     // ---- epilogue (split-K: this slice's fp32 partial goes to its slab; splitk_finalize_kernel sums and finishes)
     float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.slab) + (size_t)blockIdx.y * p.M * p.N : nullptr;
+    if (!slab) {   // pass 1: every read of the epilogue before the first store (pd_mma.h epilogue4_value)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int gm = sample * p.rows_per_sample + (y0 + wm * 4 + m) * p.Wout + x0 + fr;
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                const int gn = min(bn * BN + wn * 80 + n * 16 + fq * 4, p.N - 4);
+                acc[n][m] = epilogue4_value(p, gm, gn, sample, acc[n][m]);
+            }
+        }
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int oy = y0 + wm * 4 + m, ox = x0 + fr;
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
             const int gn = bn * BN + wn * 80 + n * 16 + fq * 4;
             if (gn >= p.N) continue;
             if (slab) *reinterpret_cast<f32x4*>(slab + (size_t)gm * p.N + gn) = acc[n][m];
-            else epilogue4(p, gm, gn, sample, tok, acc[n][m]);
+            else epilogue4_store(p, gm, gn, sample, tok, acc[n][m]);
         }
     }
 }

@@ -703,6 +703,8 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         return 1;
     }
     // otherwise split K when the tile grid cannot fill the chip (8x8 / 16x16 levels, time-embedding GEMMs)
+    bool use_ring = false;
+    int ring_tile = 0;
     if (!use_patch) {
         const size_t mk = arena.mark();
         const int tiles = gemm_tiles(p.M, m.N);
@@ -742,6 +744,13 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
             p.big_tile = 4;
         if (P == PREC_F16X2 && m.geglu && p.big_tile == 3) p.big_tile = 1;   // the 256 x 320 GEGLU tile spills with the split-operand fragments
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
+        // short reductions over 2-byte operands: the persistent ring kernel (gemm_ring.hip); 256-row tiles when they give
+        // (almost) every CU one
+        if (opt_ring > 0 && splitk == 1 && !fp8 && ktiles <= opt_ring && ring_gemm_eligible(p, P)) {
+            use_ring = true;
+            ring_tile = opt_ring_tile >= 0 ? opt_ring_tile : (((p.M + 255) / 256) * ((m.N + 159) / 160) >= 224 ? 1 : 0);
+            p.big_tile = 0;
+        }
         if (ln_out && splitk == 1 && !m.geglu && !VT) {   // this launch's own epilogue leaves the row statistics
             // the tile launch_prec (gemm.hip) takes for this launch: 256 x 320 only for linear layers over operands of the compute
             // type, otherwise big_tile 3 falls back to 256 x 160; launch_one rejects a part count that disagrees with its tile
@@ -785,10 +794,13 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     // second-generation (wave-specialised) patch kernel where it measures faster: many blocks per CU (its longer prologue
     // amortises) or the split-K 16x16 level; the 2-round 64x64 launches stay on the first generation (152 vs 142 us)
     const bool patch2 = use_patch && opt_patch2 && !f32 && !gn_coef && (patch_split > 1 || ptiles >= opt_patch2_tiles);
-    if (use_patch ? (patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream)) : launch_gemm(p, prec, stream, mid)) {
+    if (use_patch ? (patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream))
+                  : use_ring ? launch_ring_gemm(p, prec, ring_tile, stream) : launch_gemm(p, prec, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;
     }
+    if (use_ring) ++ring_launches;
+    if (profiling && mid && use_ring) HIP_OK(hipEventRecord(mid, stream));
     if (profiling) {
         if (mid) { rec.b = mid; prof.push_back(rec); }   // bracket = the contraction kernel only (no split-K finalize)
         else prof_end(rec);

@@ -289,6 +289,8 @@ struct pd_engine {
     int opt_dense_tiles = 128;
     bool opt_gn_single = true; // GroupNorm as one LDS-slab kernel where a sample's group bundle fits (32x32 and below)
     bool opt_graph = false;    // pd_ddim_sample: capture the step loop in a hipGraph and replay it on later calls with the same arguments
+    int opt_ring = 80;         // linear layers with at most this many K steps (0: off) take gemm_ring.hip's persistent LDS-DMA ring kernel
+    int opt_ring_tile = -1;    // its tile: -1 auto, 0 = 128 x 160, 1 = 256 x 160
     int opt_short_k = 20;      // linear layers with at most this many K steps: 8-wave 128x160 tile at 16 waves per CU
     bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
     int opt_patch_split_tiles = 64;
@@ -303,6 +305,7 @@ struct pd_engine {
     bool opt_patch2 = true; // 2-byte modes: the wave-specialised second-generation patch kernel (conv_patch2.hip)
     int opt_patch2_tiles = 768;   // ... for launches of at least this many blocks (and every split-K patch launch)
     long long launches = 0;
+    long long ring_launches = 0;   // launches that took gemm_ring.hip (stat "ring_launches")
     // optional per-launch timing (bench.py roofline leg): HIP events around every contraction launch
     struct ProfRec { hipEvent_t a, b; int klass; double flops; int M, N, K, taps; };
     bool profiling = false;

@@ -394,22 +394,38 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             return;
         }
     }
+    // (the 256 x 320 tile keeps reads and stores interleaved: 160 accumulator registers at the VGPR cap, the hoisted reads spill)
+    constexpr bool TWO_PASS = !GG && !(BM == 256 && BN == 320);
+    if constexpr (TWO_PASS) {
+        // pass 1 -- values: every read of the epilogue (bias, time-embedding row, residual, LayerNorm column sums), for all of
+        // the lane's groups, before the first store (pd_mma.h: a read issued behind a store waits for that store)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int gm = min(bm * BM + wm * WTM + m * 16 + fr, p.M - 1);   // rows past M: a clamped copy, never stored
+            const int sample = gm / p.rows_per_sample;
+            // folded LayerNorm / row statistics: every tile except the GEGLU-capable ones (8 x 1 waves, 160 accumulator
+            // registers at the VGPR cap: the extra epilogue state spills their accumulators -- norm3 stays a kernel of its own)
+            float ln_mean = 0.f, ln_rstd = 0.f;
+            if constexpr (LNF) {
+                if (p.ln_stats) {
+                    const float2 t = sLn[wm * WTM + m * 16 + fr];
+                    ln_mean = t.x;
+                    ln_rstd = t.y;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int gn = min(bn * BN + wn * WTN + n * 16 + fq * 4, p.N - 4);
+                acc[n][m] = epilogue4_value<MM>(p, gm, gn, sample, acc[n][m], ln_mean, ln_rstd);
+            }
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int gm = bm * BM + wm * WTM + m * 16 + fr;
         if (gm >= p.M) continue;
         const int sample = gm / p.rows_per_sample;
         const int tok = gm - sample * p.rows_per_sample;
-        // folded LayerNorm / row statistics: every tile except the GEGLU-capable ones (8 x 1 waves, 160 accumulator
-        // registers at the VGPR cap: the extra epilogue state spills their accumulators -- norm3 stays a kernel of its own)
-        float ln_mean = 0.f, ln_rstd = 0.f;
-        if constexpr (LNF) {
-            if (p.ln_stats) {
-                const float2 t = sLn[wm * WTM + m * 16 + fr];
-                ln_mean = t.x;
-                ln_rstd = t.y;
-            }
-        }
         if constexpr (GG) {
             // GEGLU: virtual columns [0,80) of each 160-column block are x, [80,160) the gate (weights interleaved at load)
             static_assert(NT % 10 == 0, "a wave's columns must be whole 160-column GEGLU blocks");
@@ -433,12 +449,26 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && WM * WN == 8) ? 4 : 2) 
             }
             continue;
         }
-        float rs = 0.f, rq = 0.f;   // producer side: this row's {sum, sum of squares} over the wave's column range
+        // pass 2 -- stores (+ producer side: this row's {sum, sum of squares} over the wave's column range)
+        float rs = 0.f, rq = 0.f;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int gn = bn * BN + wn * WTN + n * 16 + fq * 4;
             if (gn >= p.N) continue;
-            const f32x4 v = epilogue4<MM>(p, gm, gn, sample, tok, acc[n][m], ln_mean, ln_rstd);
+            f32x4 v = acc[n][m];
+            if constexpr (TWO_PASS) {
+                epilogue4_store<MM>(p, gm, gn, sample, tok, v);
+            } else {
+                float ln_mean = 0.f, ln_rstd = 0.f;
+                if constexpr (LNF) {
+                    if (p.ln_stats) {
+                        const float2 t = sLn[wm * WTM + m * 16 + fr];
+                        ln_mean = t.x;
+                        ln_rstd = t.y;
+                    }
+                }
+                v = epilogue4<MM>(p, gm, gn, sample, tok, v, ln_mean, ln_rstd);
+            }
             if constexpr (LNF) {
                 if (p.stats_out) {
                     rs += (v[0] + v[1]) + (v[2] + v[3]);

@@ -217,6 +217,9 @@ struct AttnParams {
 };
 
 int launch_gemm(const GemmParams& p, int prec, hipStream_t s, hipEvent_t mid = nullptr);   // prec: the compute type (DT_*)
+// gemm_ring.hip: persistent LDS-DMA ring GEMM for plain linear layers over 2-byte operands (tile 0: 128 x 160, 1: 256 x 160)
+bool ring_gemm_eligible(const GemmParams& p, int prec);
+int launch_ring_gemm(const GemmParams& p, int prec, int tile, hipStream_t s);
 // fp8 (e4m3) rows with one scale per row: dst[r][k] = e4m3(src[r][k] / scale[r]), scale[r] = max_k |src[r][k]| / 448 (weights of
 // the SD3 linear layers that run in PREC_FP8); src in dtype src_dt with row stride src_ld, dst row stride dst_ld >= K (pad zeroed)
 int launch_quant_rows(const void* src, int src_dt, int src_ld, void* dst, int dst_ld, float* scale, int rows, int K, hipStream_t s);

@@ -145,12 +145,15 @@ __device__ __forceinline__ f32x4 ln_apply4(const GemmParams& p, int gn, f32x4 v,
 }
 
 // (folded LayerNorm) / bias / time-embedding row / activation / scale / residual / (transposed) store of 4 consecutive
-// channels; returns the value stored (before rounding to the output type).  MM: the MMDiT extras (tanh-GELU, per-sample gate,
-// joint-buffer row remap) -- compile-time, because even as untaken branches they push the 256 x 320 tile and the
-// wave-specialised patch conv (both at the VGPR cap) into scratch.
+// channels, in two halves: epilogue4_value does every read and returns the value to store (before rounding to the output
+// type), epilogue4_store writes it.  A kernel runs the value half over ALL of a lane's accumulators before the first store:
+// loads and stores retire through one in-order counter (vmcnt), so a bias / residual read issued behind a store cannot be
+// consumed before that store is acknowledged -- interleaved, every 4-channel group pays a store round trip (measured on the
+// ring GEMM: 23 k of a block's 53 k cycles, 13 k once the reads went first).
+// MM: the MMDiT extras (tanh-GELU, per-sample gate, joint-buffer row remap) -- compile-time, because even as untaken branches
+// they push the 256 x 320 tile and the wave-specialised patch conv (both at the VGPR cap) into scratch.
 template <bool MM = false>
-__device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, int sample, int tok, f32x4 v, float ln_mean = 0.f,
-                                           float ln_rstd = 0.f) {
+__device__ __forceinline__ f32x4 epilogue4_value(const GemmParams& p, int gm, int gn, int sample, f32x4 v, float ln_mean = 0.f, float ln_rstd = 0.f) {
     if constexpr (MM) {
         if (p.a_scale) {   // PREC_FP8: per-token x per-channel operand scales
             const f32x4 ws = *reinterpret_cast<const f32x4*>(p.w_scale + gn);
@@ -187,6 +190,10 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, 
         if (p.gate) v *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)sample * p.gate_stride + gn);
     }
     if (p.R) v += load4(p.R, (size_t)gm * p.ldr + gn, p.r_dt);
+    return v;
+}
+template <bool MM = false>
+__device__ __forceinline__ void epilogue4_store(const GemmParams& p, int gm, int gn, int sample, int tok, const f32x4& v) {
     if (gn >= p.vt_begin) {
         // transposed store (attention V^T): [sample][channel][token]
         size_t base = ((size_t)sample * (p.N - p.vt_begin) + (gn - p.vt_begin)) * p.vt_ld + tok;
@@ -209,11 +216,17 @@ __device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, 
                 int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0] * inv, -448.f), 448.f), fminf(fmaxf(v[1] * inv, -448.f), 448.f), 0, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2] * inv, -448.f), 448.f), fminf(fmaxf(v[3] * inv, -448.f), 448.f), w, true);
                 *reinterpret_cast<int*>(reinterpret_cast<char*>(p.C) + crow * p.ldc + gn) = w;
-                return v;
+                return;
             }
         }
         store4(p.C, crow * p.ldc + gn, p.c_dt, v);
     }
+}
+// both halves for one group (the split-K finalize pass: one group per thread)
+template <bool MM = false>
+__device__ __forceinline__ f32x4 epilogue4(const GemmParams& p, int gm, int gn, int sample, int tok, f32x4 v, float ln_mean = 0.f,
+                                           float ln_rstd = 0.f) {
+    v = epilogue4_value<MM>(p, gm, gn, sample, v, ln_mean, ln_rstd);
+    epilogue4_store<MM>(p, gm, gn, sample, tok, v);
     return v;
 }
-

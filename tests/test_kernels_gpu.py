@@ -143,6 +143,38 @@ def test_linear(eng, M, K, N):
     assert relerr(eng.op_linear(x, w, b, a_silu=True), O.linear(O.silu(x), w, b)) < TOL[eng.prec]
 
 
+@pytest.mark.parametrize("tile", [0, 1])
+def test_linear_ring_kernel(eng, tile):
+    """gemm_ring.hip (persistent LDS-DMA ring GEMM, 2-byte modes): against the oracle and bit-identical to igemm_kernel (same MFMA
+    order per accumulator) on ragged M / N, one and several tiles per block, fewer tiles than XCDs, K from 2 to 40 steps (shapes
+    the engine does not split along K: few tiles with K >= 1024 go to the split-K path instead)."""
+    if eng.prec not in ("f16", "bf16"):
+        pytest.skip("the ring kernel stages 2-byte operands")
+    g = rng(21)
+    try:
+        for M, K, N in [(128, 128, 160), (130, 192, 164), (1000, 320, 320), (777, 960, 1920), (3000, 2560, 1920), (2048 * 9 + 5, 128, 480), (65, 640, 40), (40000, 320, 320)]:
+            x = g.standard_normal((M, K), dtype=np.float32)
+            w = (g.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+            b = g.standard_normal(N, dtype=np.float32) * 0.1
+            eng.set_option("ring", 1000); eng.set_option("ring_tile", tile)
+            n0 = eng.stat("ring_launches")
+            y = eng.op_linear(x, w, b)
+            assert eng.stat("ring_launches") == n0 + 1, ("the ring kernel did not take this layer", M, K, N)
+            eng.set_option("ring", 0)
+            y0 = eng.op_linear(x, w, b)
+            assert eng.stat("ring_launches") == n0 + 1
+            assert relerr(y, O.linear(x, w, b)) < TOL[eng.prec], (M, K, N)
+            assert np.array_equal(y, y0), (M, K, N)
+        # not eligible (K not a multiple of the 64-element stage; SiLU on load): falls back to igemm_kernel, silently and correctly
+        eng.set_option("ring", 1000)
+        n0 = eng.stat("ring_launches")
+        x = g.standard_normal((300, 72), dtype=np.float32); w = g.standard_normal((160, 72), dtype=np.float32)
+        assert relerr(eng.op_linear(x, w, None), O.linear(x, w)) < TOL[eng.prec]
+        assert eng.stat("ring_launches") == n0
+    finally:
+        eng.set_option("ring", 80); eng.set_option("ring_tile", -1)
+
+
 @pytest.mark.parametrize("M,C", [(200, 64), (64, 320), (33, 40)])
 def test_geglu(eng, M, C):
     g = rng(4)
