@@ -746,7 +746,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
         // short reductions over 2-byte operands: the persistent ring kernel (gemm_ring.hip); 256-row tiles when they give
         // (almost) every CU one
-        if (opt_ring > 0 && splitk == 1 && !fp8 && ktiles <= opt_ring && ring_gemm_eligible(p, P)) {
+        if (opt_ring > 0 && splitk == 1 && !fp8 && ktiles <= opt_ring && (p.act != 2 || opt_ring_geglu) && ring_gemm_eligible(p, P)) {
             use_ring = true;
             ring_tile = opt_ring_tile >= 0 ? opt_ring_tile : (((p.M + 255) / 256) * ((m.N + 159) / 160) >= 224 ? 1 : 0);
             p.big_tile = 0;

@@ -291,6 +291,7 @@ struct pd_engine {
     bool opt_graph = false;    // pd_ddim_sample: capture the step loop in a hipGraph and replay it on later calls with the same arguments
     int opt_ring = 80;         // linear layers with at most this many K steps (0: off) take gemm_ring.hip's persistent LDS-DMA ring kernel
     int opt_ring_tile = -1;    // its tile: -1 auto, 0 = 128 x 160, 1 = 256 x 160
+    int opt_ring_geglu = 1;    // GEGLU projections too (256 x 160 on 8 x 1 waves)
     int opt_short_k = 20;      // linear layers with at most this many K steps: 8-wave 128x160 tile at 16 waves per CU
     bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
     int opt_patch_split_tiles = 64;

@@ -49,7 +49,9 @@ __device__ unsigned long long* g_ring_stamps = nullptr;
 #define RT_ADD(acc, a, b) do { } while (0)
 #endif
 
-template <int P, int BM, int BN, int WM, int WN, int NS>
+// GG: the GEGLU epilogue (act == 2; weights pre-interleaved so that virtual columns [0, 80) of each 160-column block are x and
+// [80, 160) the gate): WN = 1, a wave owns whole blocks and writes x * gelu(gate), 80 columns per block.
+template <int P, int BM, int BN, int WM, int WN, int NS, bool GG = false>
 __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
     constexpr int NTHREADS = WM * WN * 64, RPI = NTHREADS / 8;   // RPI: tile rows one pass of all threads covers
     constexpr int A_IT = BM / RPI, B_IT = (BN + RPI - 1) / RPI, L = A_IT + B_IT;   // L: LDS-DMAs per wave and stage
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     static_assert(BM % RPI == 0 && RPI % 16 == 0 && BN % 8 == 0, "an 8-row DMA group is entirely inside or outside the tile");
     static_assert(NS >= 2 && NS <= 5 && (NS - 2) * L <= 63, "vmcnt immediates");
+    static_assert(!GG || (WN == 1 && BN == 160), "GEGLU: a wave's columns are one whole 160-column block");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = sgpr(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
                 sLn[tid] = make_float2(mean, rstd);
             }
             if (issued < G) { issue(); ++issued; }
-            if (kt == KT - 1) {
+            if (!GG && kt == KT - 1) {
                 if (p.R) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
@@ -192,6 +195,27 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
             RT_ADD(c_wait, t0, t1); RT_ADD(c_bar, t1, t2); RT_ADD(c_issue, t2, t3); RT_ADD(c_mma, t3, t4);
         }
         [[maybe_unused]] const unsigned long long t5 = RT_NOW();
+        if constexpr (GG) {
+            // ---- GEGLU epilogue: out[:, 80 bn + j] = (x_j + b_j) * gelu(g_j + b_{80 + j}); the bias reads go first (see above)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) e_bias[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + bn * BN + n * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gm = bm * BM + wm * WTM + m * 16 + fr;
+#pragma unroll
+                for (int n = 0; n < 5; ++n) {
+                    const int on = bn * 80 + n * 16 + fq * 4;
+                    const f32x4 x = acc[n][m] + e_bias[n], g = acc[n + 5][m] + e_bias[n + 5];
+                    f32x4 o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = x[c] * gelu_fast(g[c]);
+                    if (gm < p.M && on < p.Nout) store4(p.C, (size_t)gm * p.ldc + on, p.c_dt, o);
+                }
+            }
+            [[maybe_unused]] const unsigned long long t6g = RT_NOW();
+            RT_ADD(c_epi, t5, t6g);
+            continue;
+        }
         // ---- epilogue (pd_mma.h epilogue4's arithmetic): a lane holds channels gn .. gn + 3 of row gm
 #pragma unroll
         for (int n = 0; n < NT; ++n) {   // (the per-column vectors: cache hits, read once the step's fragment registers are free)
@@ -274,12 +298,12 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
 #endif
 }
 
-template <int P, int BM, int BN, int WM, int WN, int NS>
+template <int P, int BM, int BN, int WM, int WN, int NS, bool GG = false>
 int launch_ring(const GemmParams& p, int ncu, hipStream_t s) {
     constexpr int SMEM_BYTES = NS * (BM + BN) * BKB + BM * 8;
     static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
     static unsigned long long attr_done = 0;
-    auto kfn = rgemm_kernel<P, BM, BN, WM, WN, NS>;
+    auto kfn = rgemm_kernel<P, BM, BN, WM, WN, NS, GG>;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM_BYTES, &attr_done)) return 1;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN, nblk = mtiles * ntiles;
     if (p.stats_out && p.stats_parts != ntiles * WN) return 1;
@@ -293,7 +317,9 @@ int launch_ring(const GemmParams& p, int ncu, hipStream_t s) {
 // what rgemm_kernel covers: plain linear layers over 2-byte operands of the compute type
 bool ring_gemm_eligible(const GemmParams& p, int prec) {
     if (prec != DT_F16 && prec != DT_BF16) return false;
-    if (p.taps != 1 || p.a_dt != prec || p.a_silu || p.splitk > 1 || p.act == 2 || p.act == 4 || p.rowvec) return false;
+    if (p.taps != 1 || p.a_dt != prec || p.a_silu || p.splitk > 1 || p.act == 4 || p.rowvec) return false;
+    // GEGLU: whole 160-column blocks, nothing else in the epilogue
+    if (p.act == 2 && (p.N % 160 || p.R || p.ln_stats || p.stats_out || p.vt_begin < p.N || p.out_scale != 1.f)) return false;
     if (p.R && dt_size(p.r_dt) != 2) return false;   // the prefetched residual values are 2-byte
     if (p.gate || p.c_sample_rows || p.a_sample_rows || p.a_scale || p.c_scale || p.gn_coef) return false;
     if (p.K % 64 || p.K < 128 || p.K != p.Kpad || p.M < 1 || p.N % 4 || p.N < 4) return false;
@@ -302,7 +328,7 @@ bool ring_gemm_eligible(const GemmParams& p, int prec) {
     return true;
 }
 
-// tile: 0 = 128 x 160 (4 stages), 1 = 256 x 160 (3 stages); both 4 x 2 waves
+// tile: 0 = 128 x 160 (4 stages), 1 = 256 x 160 (3 stages); both 4 x 2 waves.  GEGLU layers (act 2): 256 x 160 on 8 x 1 waves.
 int launch_ring_gemm(const GemmParams& p, int prec, int tile, hipStream_t s) {
     if (!ring_gemm_eligible(p, prec)) return 1;
     static int ncu = 0;
@@ -312,6 +338,9 @@ int launch_ring_gemm(const GemmParams& p, int prec, int tile, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
         ncu = prop.multiProcessorCount;
         if (ncu < 8) return 1;
+    }
+    if (p.act == 2) {   // 256 x 160 on 8 x 1 waves (a wave: 32 rows x one GEGLU block)
+        return prec == DT_F16 ? launch_ring<DT_F16, 256, 160, 8, 1, 3, true>(p, ncu, s) : launch_ring<DT_BF16, 256, 160, 8, 1, 3, true>(p, ncu, s);
     }
     if (prec == DT_F16) return tile ? launch_ring<DT_F16, 256, 160, 4, 2, 3>(p, ncu, s) : launch_ring<DT_F16, 128, 160, 4, 2, 4>(p, ncu, s);
     return tile ? launch_ring<DT_BF16, 256, 160, 4, 2, 3>(p, ncu, s) : launch_ring<DT_BF16, 128, 160, 4, 2, 4>(p, ncu, s);

@@ -747,6 +747,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
     if (!strcmp(key, "ring")) { e->opt_ring = (int)value; return 0; }
     if (!strcmp(key, "ring_tile")) { e->opt_ring_tile = (int)value; return 0; }
+    if (!strcmp(key, "ring_geglu")) { e->opt_ring_geglu = (int)value; return 0; }
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }
     if (!strcmp(key, "patch_split")) { e->opt_patch_split = value != 0; return 0; }
     if (!strcmp(key, "patch_split_fill")) { e->opt_patch_split_fill = (int)value; return 0; }

@@ -171,8 +171,22 @@ def test_linear_ring_kernel(eng, tile):
         x = g.standard_normal((300, 72), dtype=np.float32); w = g.standard_normal((160, 72), dtype=np.float32)
         assert relerr(eng.op_linear(x, w, None), O.linear(x, w)) < TOL[eng.prec]
         assert eng.stat("ring_launches") == n0
+        # GEGLU projections (256 x 160 on 8 x 1 waves): whole 160-column blocks of the interleaved weights
+        for M, Cc in [(4096, 320), (1000 + 3, 640)]:
+            x = g.standard_normal((M, Cc), dtype=np.float32)
+            w = (g.standard_normal((8 * Cc, Cc), dtype=np.float32) / np.sqrt(Cc)).astype(np.float32)
+            b = g.standard_normal(8 * Cc, dtype=np.float32) * 0.1
+            eng.set_option("ring_geglu", 1)
+            n0 = eng.stat("ring_launches")
+            y = eng.op_linear(x, w, b, geglu=True)
+            assert eng.stat("ring_launches") == n0 + 1
+            eng.set_option("ring_geglu", 0)
+            y0 = eng.op_linear(x, w, b, geglu=True)
+            assert eng.stat("ring_launches") == n0 + 1
+            a_, gate = np.split(O.linear(x, w, b), 2, axis=-1)
+            assert relerr(y, a_ * O.gelu(gate)) < TOL[eng.prec] and np.array_equal(y, y0), (M, Cc)
     finally:
-        eng.set_option("ring", 80); eng.set_option("ring_tile", -1)
+        eng.set_option("ring", 80); eng.set_option("ring_tile", -1); eng.set_option("ring_geglu", 1)
 
 
 @pytest.mark.parametrize("M,C", [(200, 64), (64, 320), (33, 40)])
