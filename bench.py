@@ -310,7 +310,8 @@ def main():
                     frac_of_8_tb_s=by / ms_s / 1e6 / 8000.0)
             eng.set_option("profile", 0)
             eng.set_option("two_streams", 0 if args.single_stream else 1)
-            # dominant kernel by device time: igemm_kernel (every instantiation: linear / conv1x1 / generic conv3x3).
+            # dominant kernel family by device time: the generic contraction kernels -- igemm_kernel (every instantiation: linear /
+            # conv1x1 / generic conv3x3) and, since round 3, rgemm_kernel (gemm_ring.hip: the short-K linear layers).
             # Each bracket is ONE launch of that kernel (split-K finalize excluded), so avg_launch_us is comparable
             # with rocprofv3's call-weighted average over the igemm_kernel<...> rows (profiles/).
             # (the HBM-view entry above is a sub-population of igemm_kernel[linear/conv1x1], not added again)
@@ -336,7 +337,7 @@ def main():
                     uj = json.load(f)
                 mfma_util = {k: v.get("mfma_util") for k, v in uj.get("by_kernel", {}).items()}
                 util_source = "profiles/" + util_files[-1] + ": " + uj.get("definition", "")
-            result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv / linear, all instantiations)",
+            result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel + rgemm_kernel (implicit-GEMM conv / linear: every instantiation of gemm.hip and gemm_ring.hip)",
                                   "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": traffic, "traffic_source": traffic_source,
                                   "mfma_util": mfma_util, "mfma_util_source": util_source,

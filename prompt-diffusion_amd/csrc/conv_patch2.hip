@@ -340,7 +340,7 @@ int launch_patch2(const GemmParams& p, hipStream_t s) {
     const int mtiles = (p.M / (p.Hout * p.Wout)) * (p.Hout / TP) * (p.Wout / TP), ntiles = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL(kfn, dim3(mtiles * ntiles, p.splitk > 1 ? p.splitk : 1), dim3(NT), G::SMEM, s, p);
     if (hipGetLastError() != hipSuccess) return 1;
-    return p.splitk > 1 ? launch_splitk_finalize(p, s) : 0;
+    return (p.splitk > 1 && !p.defer_finalize) ? launch_splitk_finalize(p, s) : 0;
 }
 
 }  // namespace

@@ -657,6 +657,9 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     }
     const bool plain = !gx.gate && !gx.c_sample_rows && !gx.a_sample_rows && !gx.c_scale;
     gx = GemmExtra{};
+    SlabDefer* defer = gx_defer;
+    gx_defer = nullptr;
+    if (defer) defer->active = false;
     // a handful of fp32 rows against a wide weight matrix: stream the weights once (gemm.hip's tiles would spend a 128-row
     // tile on <= 4 rows and run at a third of the HBM rate)
     if (opt_gemv && plain && p.M <= 4 && m.taps == 1 && in.dt == DT_F32 && out.dt == DT_F32 && !R && !rowvec && !VT && act == 0 &&
@@ -725,6 +728,11 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         }
         p.splitk = splitk;
         p.tile_cnt = (splitk > 1 && opt_splitk_fused) ? tile_cnt : nullptr;
+        // the consumer sums the slabs itself (SlabDefer): plain bias / time-embedding epilogue only
+        if (defer && defer->allow && splitk > 1 && !p.tile_cnt && p.slab && plain && act == 0 && scale == 1.f && !R && !VT && !ln_in && !ln_out && !m.geglu) {
+            p.defer_finalize = 1;
+            defer->active = true;
+        }
         // 256-row tiles when they still give every CU a block (1 block of 8 waves per CU)
         p.big_tile = (opt_bigtile && splitk == 1 && ((p.M + 255) / 256) * ((m.N + 159) / 160) >= 256) ? 1 : 0;
         if (dense8 && tiles < opt_splitk_tiles) p.big_tile = 2;
@@ -743,7 +751,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
             ((p.M + 255) / 256) * (m.N / 192) >= 192)
             p.big_tile = 4;
         if (P == PREC_F16X2 && m.geglu && p.big_tile == 3) p.big_tile = 1;   // the 256 x 320 GEGLU tile spills with the split-operand fragments
-        arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
+        if (!p.defer_finalize) arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
         // short reductions over 2-byte operands: the persistent ring kernel (gemm_ring.hip); 256-row tiles when they give
         // (almost) every CU one
         if (opt_ring > 0 && splitk == 1 && !fp8 && ktiles <= opt_ring && (p.act != 2 || opt_ring_geglu) && ring_gemm_eligible(p, P)) {
@@ -771,7 +779,12 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         p.slab = arena.alloc((size_t)patch_split * p.M * m.N * sizeof(float));
         p.splitk = patch_split;
         if (!arena.dry && arena.top > arena.cap) { pd_set_error("no workspace for the conv split-K slabs"); return 1; }
-        arena.release(mk);   // stream-ordered: dead once the finalize pass has run
+        if (defer && defer->allow && plain && act == 0 && scale == 1.f && !R && !VT && !ln_in && !ln_out) {
+            p.defer_finalize = 1;
+            defer->active = true;
+        } else {
+            arena.release(mk);   // stream-ordered: dead once the finalize pass has run
+        }
     }
     if (arena.dry) return 0;
     PD_TRY(check_arena());
@@ -800,6 +813,10 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         return 1;
     }
     if (use_ring) ++ring_launches;
+    if (defer && defer->active) {
+        defer->slabs = reinterpret_cast<const float*>(p.slab); defer->nslab = p.splitk;
+        defer->bias = p.bias; defer->rowvec = p.rowvec; defer->rowvec_stride = p.rowvec_stride;
+    }
     if (profiling && mid && use_ring) HIP_OK(hipEventRecord(mid, stream));
     if (profiling) {
         if (mid) { rec.b = mid; prof.push_back(rec); }   // bracket = the contraction kernel only (no split-K finalize)
@@ -838,7 +855,20 @@ int pd_engine::gn_stats(const Act& x, int& nchunk) {
     return 0;
 }
 
-int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu) {
+int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu, const SlabDefer* from_slabs) {
+    if (from_slabs && from_slabs->active) {   // x was never written: the producing GEMM's split-K slabs are the input
+        if (!(opt_gn_single && gn_fused_bundle(x.dt, x.H * x.W, x.C, 32))) { pd_set_error("internal: deferred split-K slabs without the single-kernel GroupNorm"); return 1; }
+        if (arena.dry) return 0;
+        PD_TRY(check_arena());
+        ++launches;
+        ++gn_from_slabs;
+        if (launch_gn_fused_slabs(from_slabs->slabs, from_slabs->nslab, from_slabs->bias, from_slabs->rowvec, from_slabs->rowvec_stride, x.dt, y.p, y.dt, g, b,
+                                  x.B, x.H * x.W, x.C, 32, eps, silu ? 1 : 0, stream)) {
+            pd_set_error("groupnorm (single kernel, split-K slabs) launch failed (C=%d)", x.C);
+            return 1;
+        }
+        return 0;
+    }
     if (opt_gn_single && gn_fused_bundle(x.dt, x.H * x.W, x.C, 32)) {   // slab fits in LDS: one kernel, one read
         if (arena.dry) return 0;
         PD_TRY(check_arena());
@@ -863,7 +893,7 @@ int pd_engine::groupnorm(const Act& x, Act& y, const float* g, const float* b, f
 // conv3x3(act(GroupNorm(x))): when the conv runs on the LDS-patch kernel the normalisation (+SiLU) is applied while
 // the input patch is staged, so the normalised tensor is never written to HBM; otherwise GroupNorm runs as its own pass.
 int pd_engine::conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, const float* b, float eps, bool silu,
-                       const Act* R, const float* rowvec, int rowvec_stride) {
+                       const Act* R, const float* rowvec, int rowvec_stride, SlabDefer* out_defer, const SlabDefer* in_slabs) {
     GemmParams q{};
     q.M = (int)out.rows(); q.N = c.m.N; q.K = c.m.K; q.taps = c.m.taps; q.Cin = c.m.cin_pad; q.stride = c.stride;
     q.Hin = x.H; q.Win = x.W; q.Hout = out.H; q.Wout = out.W; q.a_dt = x.dt; q.vt_begin = INT_MAX; q.splitk = 1;
@@ -871,11 +901,13 @@ int pd_engine::conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, c
     if (!fuse) {
         const size_t mk = arena.mark();
         Act a = new_act(x.B, x.H, x.W, x.C, T);
-        PD_TRY(groupnorm(x, a, g, b, eps, silu));
+        PD_TRY(groupnorm(x, a, g, b, eps, silu, in_slabs));
+        gx_defer = out_defer;
         PD_TRY(conv(c, a, out, 0, 1.f, R, rowvec, rowvec_stride));
-        arena.release(mk);
+        if (!(out_defer && out_defer->active)) arena.release(mk);   // deferred: the slabs sit above `a`; the caller's mark frees both
         return 0;
     }
+    if (in_slabs && in_slabs->active) { pd_set_error("internal: deferred split-K slabs in front of a GroupNorm-fused conv"); return 1; }
     int nchunk = 1;
     PD_TRY(gn_stats(x, nchunk));
     const size_t mk = arena.mark();
@@ -940,13 +972,17 @@ int pd_engine::resblock(const ResW& r, const Act& x, Act& out, const float* embr
     out = new_act(x.B, x.H, x.W, r.cout, S);
     const size_t mk = arena.mark();
     Act h = new_act(x.B, x.H, x.W, r.cout, T);
-    PD_TRY(conv_gn(r.conv1, x, h, r.gn1_g, r.gn1_b, r.eps, true, nullptr, embrow, emb_stride));
+    // conv1's only reader is norm2: when conv1 runs split-K and norm2 is the single-kernel GroupNorm (16x16 / 8x8 levels), that
+    // kernel sums the slabs itself -- no finalize pass, h is never written
+    SlabDefer d;
+    d.allow = opt_slab_gn && !opt_gn_fuse && opt_gn_single && h.dt == T && gn_fused_bundle(T, x.H * x.W, r.cout, 32) > 0;
+    PD_TRY(conv_gn(r.conv1, x, h, r.gn1_g, r.gn1_b, r.eps, true, nullptr, embrow, emb_stride, &d));
     Act skip = x;
     if (r.has_skip) {
         skip = new_act(x.B, x.H, x.W, r.cout, S);
         PD_TRY(conv(r.skip, x, skip));
     }
-    PD_TRY(conv_gn(r.conv2, h, out, r.gn2_g, r.gn2_b, r.eps, true, &skip, nullptr, 0));
+    PD_TRY(conv_gn(r.conv2, h, out, r.gn2_g, r.gn2_b, r.eps, true, &skip, nullptr, 0, nullptr, &d));
     arena.release(mk);
     return 0;
 }

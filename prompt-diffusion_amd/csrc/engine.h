@@ -306,6 +306,7 @@ struct pd_engine {
     bool opt_patch2 = true; // 2-byte modes: the wave-specialised second-generation patch kernel (conv_patch2.hip)
     int opt_patch2_tiles = 768;   // ... for launches of at least this many blocks (and every split-K patch launch)
     long long launches = 0;
+    long long gn_from_slabs = 0;   // GroupNorm launches that summed a split-K GEMM's slabs (stat "gn_from_slabs")
     long long ring_launches = 0;   // launches that took gemm_ring.hip (stat "ring_launches")
     // optional per-launch timing (bench.py roofline leg): HIP events around every contraction launch
     struct ProfRec { hipEvent_t a, b; int klass; double flops; int M, N, K, taps; };
@@ -357,6 +358,12 @@ struct pd_engine {
     int sd3_block(const Sd3BlockW& b, Act& x, Act& c, const Act& modbuf, const Act& qk, const Act& vt, const Act* pre_add = nullptr);
     int sd3_forward(const Sd3Io& io, float* v_out_dev, int control_index, float* control_out_dev);
     // one-shot extras of the next gemm() call (MMDiT: gated residual, joint-buffer row remap)
+    // A split-K conv whose only consumer is a single-kernel GroupNorm (resblock conv1 -> norm2 at the 16x16 / 8x8 levels) leaves its
+    // slabs un-summed: `allow` is set by the caller of gemm(), `active` by gemm() when it did skip the finalize pass; the slabs
+    // stay on the workspace stack until the caller's own mark is released.
+    struct SlabDefer { bool allow = false, active = false; const float* slabs = nullptr; int nslab = 0; const float* bias = nullptr; const float* rowvec = nullptr; int rowvec_stride = 0; };
+    SlabDefer* gx_defer = nullptr;   // one-shot, like gx: consumed (and cleared) by the next gemm()
+    int opt_slab_gn = 1;             // the fusion above (option "slab_gn")
     struct GemmExtra { const float* a_scale = nullptr; const float* c_scale = nullptr; const float* gate = nullptr; int gate_stride = 0, c_sample_rows = 0, c_row_off = 0, vt_tok_off = 0, a_sample_rows = 0, a_row_off = 0; } gx;
     int opt_sd3_fp8 = 0;       // 0 off, 1: the AdaLN-fed projections, 2: also the feed-forward-out projections (e4m3 GELU output under a norm bound)  // SD3 path: QKV and feed-forward-in projections in PREC_FP8 (e4m3 operands, per-row scales)
     bool sd3_fp8_dirty = true;
@@ -381,10 +388,10 @@ struct pd_engine {
     bool st_tail_on(const STW& s, int rows_per_sample) const;
     int gn_stats(const Act& x, int& nchunk);
     int conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, const float* b, float eps, bool silu, const Act* R,
-                const float* rowvec, int rowvec_stride);
+                const float* rowvec, int rowvec_stride, SlabDefer* out_defer = nullptr, const SlabDefer* in_slabs = nullptr);
     int conv(const ConvW& c, const Act& in, Act& out, int act = 0, float scale = 1.f, const Act* R = nullptr,
              const float* rowvec = nullptr, int rowvec_stride = 0, int ups = 0);
-    int groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu);
+    int groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu, const SlabDefer* from_slabs = nullptr);
     int layernorm(const Act& x, Act& y, const float* g, const float* b);
     int resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride);
     int transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv);

@@ -518,7 +518,7 @@ int launch_one(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), SMEM_BYTES, s, p);
     if (hipGetLastError() != hipSuccess) return 1;
     if (mid) (void)hipEventRecord(mid, s);   // profiling: end of the contraction kernel proper
-    if (p.splitk > 1 && !p.tile_cnt) {
+    if (p.splitk > 1 && !p.tile_cnt && !p.defer_finalize) {
         long long total = (long long)p.M * (p.N / 4);
         int nb = (int)((total + 255) / 256);
         if (nb > 4096) nb = 4096;

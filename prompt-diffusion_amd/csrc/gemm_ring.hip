@@ -95,6 +95,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
     };
     int pj = 0, pkt = 0, pslot = 0;
     auto issue = [&]() __attribute__((always_inline)) {
+#ifdef PD_KO_DMA   // diagnostic build (tools/micro/ring_stamp.hip): no operand ever requested -- what do barrier + ds_read + MFMA take?
+        if (++pkt == KT) { pkt = 0; ++pj; }
+        pslot = pslot + 1 == NS ? 0 : pslot + 1;
+        return;
+#endif
         const char* As = reinterpret_cast<const char*>(p.A) + (size_t)pkt * BKB;
         const char* Ws = reinterpret_cast<const char*>(p.W) + (size_t)pkt * BKB;
         const unsigned dst = lds0 + (unsigned)pslot * STAGE + (unsigned)wave * 8 * BKB;
@@ -131,9 +136,21 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
         for (int ks = 0; ks < 2; ++ks) {
             uint4 af[MT], wf[NT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, ks * 4 + fq));
+            for (int m = 0; m < MT; ++m) {
+#ifdef PD_KO_DSREAD   // diagnostic build: MFMAs on whatever the registers hold
+                asm volatile("" : "=v"(af[m]));
+#else
+                af[m] = *reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, ks * 4 + fq));
+#endif
+            }
 #pragma unroll
-            for (int n = 0; n < NT; ++n) wf[n] = *reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, ks * 4 + fq));
+            for (int n = 0; n < NT; ++n) {
+#ifdef PD_KO_DSREAD
+                asm volatile("" : "=v"(wf[n]));
+#else
+                wf[n] = *reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, ks * 4 + fq));
+#endif
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll

@@ -180,10 +180,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const void* __rest
 // normalises out of LDS.  One read + one write of the tensor and one launch instead of two reads + one write in two.
 constexpr int GNF_THREADS = 960;   // 15 waves; divisible by 5, 10, 15 (vectors per pixel of the bundles that occur)
 
-template <int XD, int YD>
+// SLAB: the input is not a stored tensor but the fp32 partial sums of a split-K GEMM (nslab slabs of [rows][C], slab_stride
+// floats apart) plus its bias and per-sample row (the time-embedding projection): the value a thread would have loaded is
+// rebuilt as round_XD(slab_0 + slab_1 + ... + bias + row) -- splitk_finalize_kernel's order and rounding, bit for bit -- so the
+// GEMM's finalize pass and the tensor it would have written disappear (x is unused).
+struct GnSlabSrc { const float* slabs; long long slab_stride; const float* bias; const float* row; int nslab, row_stride; };
+
+template <int XD, int YD, bool SLAB = false>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                int HW, int C, int groups, int BC, float eps, int do_silu) {
+                                                                int HW, int C, int groups, int BC, float eps, int do_silu, GnSlabSrc src) {
     constexpr bool XF32 = XD == DT_F32, YF32 = YD == DT_F32;
     constexpr int VEC = XF32 ? 4 : 8;
     constexpr int EX = XF32 ? 4 : 2;
@@ -212,7 +218,23 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const void* __res
     for (int j = 0; j < VEC; ++j) { ds[j] = 0.0; dq[j] = 0.0; s[j] = 0.f; q[j] = 0.f; }
     int cnt = 0;
     for (int p = pr; p < HW; p += rows_par) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C * EX);
+        uint4 raw;
+        if constexpr (SLAB) {
+            const float* sp = src.slabs + ((size_t)b * HW + p) * C + c0;
+            float acc[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; j += 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(sp + j);
+                for (int k = 1; k < src.nslab; ++k) t += *reinterpret_cast<const f32x4*>(sp + (size_t)k * src.slab_stride + j);
+                if (src.bias) t += *reinterpret_cast<const f32x4*>(src.bias + c0 + j);
+                if (src.row) t += *reinterpret_cast<const f32x4*>(src.row + (size_t)b * src.row_stride + c0 + j);
+                acc[j] = t[0]; acc[j + 1] = t[1]; acc[j + 2] = t[2]; acc[j + 3] = t[3];
+            }
+            if constexpr (XF32) raw = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
+            else raw = pack8<XD>(acc);
+        } else {
+            raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C * EX);
+        }
         *reinterpret_cast<uint4*>(slab + ((size_t)p * nvec + v) * 16) = raw;
         float f[VEC];
         if constexpr (XF32) {
@@ -519,7 +541,25 @@ int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gam
         static unsigned long long attr_done = 0;   // one per (XD, YD) instantiation of this lambda
         auto kfn = gn_fused_kernel<decltype(XD)::value, decltype(YD)::value>;
         if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), 104 * 1024, &attr_done)) { fail = true; return; }
-        hipLaunchKernelGGL(kfn, grid, dim3(GNF_THREADS), smem, s, x, y, gamma, beta, HW, C, groups, BC, eps, do_silu);
+        hipLaunchKernelGGL(kfn, grid, dim3(GNF_THREADS), smem, s, x, y, gamma, beta, HW, C, groups, BC, eps, do_silu, GnSlabSrc{});
+    });
+    return ok && !fail && hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int launch_gn_fused_slabs(const float* slabs, int nslab, const float* bias, const float* rowvec, int rowvec_stride, int x_dt, void* y, int y_dt,
+                          const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps, int do_silu, hipStream_t s) {
+    const int BC = gn_fused_bundle(x_dt, HW, C, groups);
+    if (!BC || !slabs || nslab < 1 || C % 4) return 1;
+    const int EX = x_dt == DT_F32 ? 4 : 2;
+    const size_t smem = (size_t)HW * BC * EX + (GNF_THREADS / 64) * 4 * 2 * sizeof(double);
+    const dim3 grid(B * (C / BC));
+    const GnSlabSrc src{slabs, (long long)B * HW * C, bias, rowvec, nslab, rowvec_stride};
+    bool fail = false;
+    const bool ok = dispatch_xy(x_dt, y_dt, [&](auto XD, auto YD) {
+        static unsigned long long attr_done = 0;   // one per (XD, YD) instantiation of this lambda
+        auto kfn = gn_fused_kernel<decltype(XD)::value, decltype(YD)::value, true>;
+        if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), 104 * 1024, &attr_done)) { fail = true; return; }
+        hipLaunchKernelGGL(kfn, grid, dim3(GNF_THREADS), smem, s, static_cast<const void*>(nullptr), y, gamma, beta, HW, C, groups, BC, eps, do_silu, src);
     });
     return ok && !fail && hipGetLastError() == hipSuccess ? 0 : 1;
 }

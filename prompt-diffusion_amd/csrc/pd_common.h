@@ -170,6 +170,7 @@ struct GemmParams {
     int splitk;           // >1: grid.y slices K; each slice stores an fp32 slab, a finalize pass sums them + epilogue
     void* slab;           // [splitk][M][N] fp32 workspace
     int* tile_cnt;        // split-K: one zeroed counter per 128x160 tile -> finalize fused into the last-arriving slice; null: separate pass
+    int defer_finalize;   // split-K without tile counters: 1 = no finalize pass here -- the consumer (norm.hip gn_fused_kernel, slab mode) sums the slabs
     int big_tile;         // tile: 0 128 x 160 (4 waves), 1 256 x 160, 2 128 x 160 on 8 waves (short K), 3 256 x 320, 4 256 x 192
     const float* gn_coef; // conv_patch only: [B][Cin][2] GroupNorm coefficients applied (+SiLU) while staging A; null = none
     int gn_silu;
@@ -260,6 +261,10 @@ int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* pa
 int gn_fused_bundle(int x_dt, int HW, int C, int groups);   // norm.hip: > 0 when the single-kernel GroupNorm applies
 int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta, int B, int HW, int C, int groups,
                     float eps, int do_silu, hipStream_t s);
+// the same kernel fed by a split-K GEMM's fp32 slabs instead of a stored tensor: x[row][c] = round_T(sum_s slab[s][row][c] + bias[c] +
+// rowvec[sample][c]) -- splitk_finalize_kernel's arithmetic and rounding, so the result is bit-identical to finalize + launch_gn_fused
+int launch_gn_fused_slabs(const float* slabs, int nslab, const float* bias, const float* rowvec, int rowvec_stride, int x_dt, void* y, int y_dt,
+                          const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps, int do_silu, hipStream_t s);
 int launch_gn_coef(const double* partial, const float* gamma, const float* beta, float* coef, int B, int HW, int C, int groups,
                    int nchunk, float eps, hipStream_t s);
 // {sum, sum of squares} of every row: the single-part form of the LayerNorm statistics above (producers whose epilogue

@@ -745,6 +745,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "st_fuse")) { e->opt_st_fuse = value != 0; e->ln_dirty = true; return 0; }
     if (!strcmp(key, "two_streams")) { e->opt_two_streams = value != 0; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
+    if (!strcmp(key, "slab_gn")) { e->opt_slab_gn = (int)value; return 0; }
     if (!strcmp(key, "ring")) { e->opt_ring = (int)value; return 0; }
     if (!strcmp(key, "ring_tile")) { e->opt_ring_tile = (int)value; return 0; }
     if (!strcmp(key, "ring_geglu")) { e->opt_ring_geglu = (int)value; return 0; }
@@ -796,6 +797,7 @@ int64_t pd_get_stat(pd_engine* e, const char* key) {
     if (!strcmp(key, "workspace_bytes")) return (int64_t)e->arena.cap;
     if (!strcmp(key, "weight_bytes")) return (int64_t)e->weight_bytes;
     if (!strcmp(key, "launches")) return (int64_t)e->launches;
+    if (!strcmp(key, "gn_from_slabs")) return (int64_t)e->gn_from_slabs;
     if (!strcmp(key, "ring_launches")) return (int64_t)e->ring_launches;   // of which: gemm_ring.hip's persistent ring kernel
     if (!strcmp(key, "steps")) return (int64_t)e->ses.S;
     if (!strcmp(key, "event_overhead_ns")) return (int64_t)(e->prof_overhead_ms * 1e6f);

@@ -328,6 +328,31 @@ def test_sd15_headline_schedule_per_step(golden_dir, tag, prec):
     e.close()
 
 
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_split_k_slabs_into_groupnorm_is_bit_identical(prec):
+    """Option 'slab_gn' (default on): where a ResBlock's conv1 runs split-K and norm2 is the single-kernel GroupNorm (the
+    16x16 / 8x8 levels), that kernel sums the fp32 slabs itself in splitk_finalize_kernel's order and rounding, so the finalize
+    pass and the tensor between them disappear.  SD1.5 at 256x256 (latent 32x32: levels 32 / 16 / 8 / 4), batch 2, two guided
+    steps: the latents must equal the unfused path's bit for bit, and the fused path must really be taken (fewer launches)."""
+    cfg = W.SD15
+    e = E.Engine(cfg, precision=prec)
+    e.init_random_weights(7)
+    inp = W.synth_inputs(cfg, 2, 32, 32, seed=11)
+    kw = dict(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"], query=inp["query"], steps=2, cfg_scale=7.5)
+    try:
+        e.set_option("slab_gn", 1)
+        fused = e.ddim_sample(**kw)
+        e.set_option("slab_gn", 0)
+        plain = e.ddim_sample(**kw)
+        n_fused, n_plain = e.stat("gn_from_slabs"), None
+    finally:
+        e.set_option("slab_gn", 1)
+        e.close()
+    assert np.isfinite(fused).all()
+    assert n_fused > 0, "no ResBlock took the fused path at these sizes"
+    np.testing.assert_array_equal(fused, plain)
+
+
 def test_graph_replay_is_bit_identical(tiny_f32):
     """Option 'graph': the step loop of pd_ddim_sample captured in a hipGraph (both streams, fork/join events) and
     replayed on later calls with the same arguments.  Capture, replay, replay-with-new-inputs and a changed argument

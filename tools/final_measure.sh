@@ -12,7 +12,7 @@ grep -a '^{' $O/bench_under_rocprof.log | tail -1 > $O/${R}_bench_under_rocprof.
 rm -rf $O/stats
 python tools/kstats_table.py $O/${R}_bench_kernel_stats.csv 200 > $O/${R}_bench_kernel_table.txt
 echo "[final] kernel stats done"
-KRE="igemm_kernel|conv3x3_patch|attn2_kernel|st_tail_kernel|st_front_kernel"
+KRE="igemm_kernel|rgemm_kernel|conv3x3_patch|attn2_kernel|st_tail_kernel|st_front_kernel"
 PMC_CMD="python bench.py --single-stream --steps 1 --warmup 0 --ddim-steps 20 --no-cpu-baseline --no-profile --no-f32 --no-parity --no-sd3"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$KRE" --output-format csv -d $O/fetch -- $PMC_CMD > $O/fetch.log 2>&1
 echo "[final] FETCH_SIZE pass done"
@@ -31,6 +31,7 @@ PD_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-basel
 echo "[final] --gpus 2 rehearsal done"
 python bench.py --batch 1 --steps 3 --no-cpu-baseline --no-profile --no-f32 --no-parity --no-sd3 > $O/bench_bs1.log 2>&1
 tail -1 $O/bench_bs1.log > $O/${R}_bench_bs1.json
+cp $O/${R}_pmc_traffic.json $O/${R}_pmc_mfma_util.json profiles/   # the default line below quotes the counters measured in THIS call
 python bench.py > $O/bench_default.log 2>&1
 tail -1 $O/bench_default.log > $O/${R}_bench_default.json
 head -c 700 $O/${R}_bench_default.json

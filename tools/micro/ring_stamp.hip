@@ -1,6 +1,7 @@
 // Diagnostic build of gemm_ring.hip with s_memtime accumulators (wave 0 of every block): where do a block's cycles go?
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPD_STAMP -Iprompt-diffusion_amd/csrc tools/micro/ring_stamp.hip -o /tmp/ring_stamp && /tmp/ring_stamp
 // Read the SHARES, not the lengths: the stamps' fences forbid overlaps the product build has.
+// Without -DPD_STAMP: the product kernel, launch times only.  Knock-outs (timing only, results are garbage): -DPD_KO_DMA, -DPD_KO_DSREAD.
 #include "../../prompt-diffusion_amd/csrc/gemm_ring.hip"
 #include <algorithm>
 #include <cstdio>
@@ -9,10 +10,12 @@
 
 int main() {
     struct Shape { int M, K, N, res, tile; };
-    const Shape shapes[] = {{16384, 640, 640, 0, 0}, {16384, 640, 640, 0, 1}, {16384, 640, 640, 1, 1}, {4096, 1280, 1280, 1, 0}, {16384, 2560, 640, 1, 1}, {16384, 640, 1920, 0, 1}};
+    const Shape shapes[] = {{16384, 640, 640, 0, 0}, {16384, 640, 640, 0, 1}, {16384, 640, 640, 1, 1}, {4096, 1280, 1280, 1, 0}, {16384, 2560, 640, 1, 1}, {16384, 640, 1920, 0, 1}, {16384, 5120, 2560, 0, 1}, {8192, 8192, 8192, 0, 1}};
     unsigned long long* stamps;
     hipMalloc(&stamps, 256 * 8 * 8);
+#ifdef PD_STAMP
     hipMemcpyToSymbol(HIP_SYMBOL(g_ring_stamps), &stamps, sizeof(stamps));
+#endif
     for (const Shape& sh : shapes) {
         void *a, *w, *c, *r;
         float* bias;
@@ -33,6 +36,10 @@ int main() {
         hipDeviceSynchronize();
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
+#ifndef PD_STAMP
+        printf("M=%d K=%d N=%d res=%d tile=%d: %.1f us per launch (%.0f TF/s)\n", sh.M, sh.K, sh.N, sh.res, sh.tile, ms * 100.0, 2.0 * sh.M * sh.K * sh.N / (ms * 1e-4) / 1e12);
+        continue;
+#endif
         std::vector<unsigned long long> h(256 * 8);
         hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
         auto med = [&](int slot, bool life) {

@@ -4,7 +4,7 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per
 counters are in KB.  usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> "<command that was profiled>" """
 import collections, csv, glob, json, sys
 
-FAMILIES = ("igemm_kernel<", "conv3x3_patch_kernel<", "conv3x3_patch2_kernel<", "attn2_kernel", "gn_apply_kernel<", "gn_stats_kernel<",
+FAMILIES = ("igemm_kernel<", "rgemm_kernel<", "conv3x3_patch_kernel<", "conv3x3_patch2_kernel<", "attn2_kernel", "gn_apply_kernel<", "gn_stats_kernel<",
             "gn_fused_kernel<", "layernorm_kernel<", "splitk_finalize_kernel", "concat_add_kernel", "st_tail_kernel<", "st_front_kernel<")
 
 
@@ -33,6 +33,10 @@ for f in FAMILIES:
     fk, wk = fetch[f] / nf[f], write[f] / max(nw[f], 1)
     out["by_kernel"][name] = {"launches": nf[f], "fetch_size_kb_raw": fk, "write_size_kb": wk,
                               "hbm_bytes_per_launch": (2 * fk + wk) * 1024}
-out["igemm_kernel_hbm_bytes_per_launch"] = out["by_kernel"]["igemm_kernel"]["hbm_bytes_per_launch"]
+# the family bench.py's roofline object is about: every launch of the generic contraction kernels -- igemm_kernel (gemm.hip) and
+# rgemm_kernel (gemm_ring.hip, round 3: the short-K linear layers) -- launch-weighted
+gk = [out["by_kernel"][k] for k in ("igemm_kernel", "rgemm_kernel") if k in out["by_kernel"]]
+out["igemm_kernel_hbm_bytes_per_launch"] = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in gk) / sum(k["launches"] for k in gk)
+out["igemm_kernel_hbm_bytes_per_launch_covers"] = "igemm_kernel + rgemm_kernel, launch-weighted"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["by_kernel"], indent=1))
