@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     for (int n = 0; n < 5; ++n)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    [[maybe_unused]] unsigned long long c_top = 0, c_mma = 0, c_wst = 0, c_bar = 0;
+    [[maybe_unused]] unsigned long long c_top = 0, c_mma = 0, c_wst = 0, c_bar = 0, c_busy = 0;
     [[maybe_unused]] const unsigned long long t_begin = CT_NOW();
 
     // ---- prologue: patch 0, weight tile of unit 0 in LDS; unit 1's weights in flight
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         __syncthreads();
         [[maybe_unused]] const unsigned long long t4 = CT_NOW();
         CT_ADD(c_top, t0, t1); CT_ADD(c_mma, t1, t2); CT_ADD(c_wst, t2, t3); CT_ADD(c_bar, t3, t4);
+        CT_ADD(c_busy, t0, t3);
     };
     [[maybe_unused]] const unsigned long long t_loop = CT_NOW();
     for (int c = 0; c < nchunks; ++c) {
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         }
     }
 #ifdef PD_STAMP
+    if (lane == 0 && g_conv_stamps) g_conv_stamps[(size_t)gridDim.x * 10 + (size_t)blockIdx.x * 8 + wave] = c_busy;   // per wave: release -> arrival
     if (threadIdx.x == 0 && g_conv_stamps) {
         unsigned long long* o = g_conv_stamps + (size_t)blockIdx.x * 10;
         const unsigned long long t_end = CT_NOW();

@@ -1,8 +1,14 @@
 // Diagnostic build of conv_patch.hip with s_memtime accumulators (wave 0 of every block): where do a block's cycles go?
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPD_STAMP -w -Iprompt-diffusion_amd/csrc tools/micro/conv_stamp.hip -o /tmp/conv_stamp && /tmp/conv_stamp
 // Read the SHARES, not the lengths: the stamps' fences forbid overlaps the product build has.
-// Without -DPD_STAMP the kernel is the product build and only the launch time is printed.
+// Without -DPD_STAMP the kernel is the product build and only the launch time is printed.  -DCOLD: every launch reads operands that
+// left the caches long ago (10 operand sets in turn); -DCONST_DATA: hipMemset operands instead of random ones (10-15 % faster: the
+// matrix pipe's power draw, and with it the clock, depends on the data -- never benchmark a kernel on constant fills).
+#ifdef CONV_SRC_OLD   // A/B against another version of the kernel: put it at tools/micro/conv_patch_old.hip (not committed)
+#include "conv_patch_old.hip"
+#else
 #include "../../prompt-diffusion_amd/csrc/conv_patch.hip"
+#endif
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -10,11 +16,20 @@
 
 int launch_splitk_finalize(const GemmParams&, hipStream_t) { return 0; }   // (gemm.hip's; not linked here, never reached: no split-K below)
 
+// random fp16 operands in [-0.5, 0.5): the matrix pipe's power draw -- and with it the clock the chip settles at -- depends on the data;
+// constant fills (hipMemset) run 10-15 % faster than anything the network ever sees
+static void fill_random(void* p, size_t bytes, unsigned seed) {
+    std::vector<uint16_t> h(bytes / 2);
+    unsigned x = seed;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; const float f = ((int)(x >> 9 & 0x3fff) - 8192) / 16384.0f; _Float16 hf = (_Float16)f; v = *reinterpret_cast<uint16_t*>(&hf); }
+    hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice);
+}
+
 int main() {
     struct Shape { int B, H, Cin, Cout, res; };
     const Shape shapes[] = {{16, 64, 320, 320, 1}, {16, 64, 320, 320, 0}, {16, 32, 640, 640, 1}, {16, 64, 640, 320, 1}, {16, 16, 1280, 1280, 1}};
     unsigned long long* stamps;
-    hipMalloc(&stamps, 4096 * 10 * 8);
+    hipMalloc(&stamps, 4096 * 18 * 8);
 #ifdef PD_STAMP
     hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &stamps, sizeof(stamps));
 #endif
@@ -24,7 +39,12 @@ int main() {
         void *a, *w, *c, *r;
         float* bias;
         hipMalloc(&a, M * sh.Cin * 2); hipMalloc(&w, (size_t)sh.Cout * K * 2); hipMalloc(&c, M * sh.Cout * 2); hipMalloc(&r, M * sh.Cout * 2); hipMalloc(&bias, sh.Cout * 4);
-        hipMemset(a, 0x11, M * sh.Cin * 2); hipMemset(w, 0x12, (size_t)sh.Cout * K * 2); hipMemset(r, 0x13, M * sh.Cout * 2); hipMemset(bias, 0, sh.Cout * 4);
+#ifdef CONST_DATA
+        hipMemset(a, 0x11, M * sh.Cin * 2); hipMemset(w, 0x12, (size_t)sh.Cout * K * 2); hipMemset(r, 0x13, M * sh.Cout * 2);
+#else
+        fill_random(a, M * sh.Cin * 2, 1); fill_random(w, (size_t)sh.Cout * K * 2, 2); fill_random(r, M * sh.Cout * 2, 3);
+#endif
+        hipMemset(bias, 0, sh.Cout * 4);
         GemmParams p;
         memset(&p, 0, sizeof(p));
         p.A = a; p.W = w; p.C = c; p.R = sh.res ? r : nullptr; p.bias = bias;
@@ -34,14 +54,27 @@ int main() {
         const int blocks = conv_patch_tiles(p, DT_F16);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
+#ifdef COLD   // every launch reads inputs that left the caches long ago: NB operand sets (> the 256 MB Infinity Cache together) in turn
+        constexpr int NB = 10;
+        void *as[NB], *rs[NB], *cs[NB];
+        for (int i = 0; i < NB; ++i) { hipMalloc(&as[i], M * sh.Cin * 2); hipMalloc(&rs[i], M * sh.Cout * 2); hipMalloc(&cs[i], M * sh.Cout * 2); hipMemcpy(as[i], a, M * sh.Cin * 2, hipMemcpyDeviceToDevice); hipMemcpy(rs[i], r, M * sh.Cout * 2, hipMemcpyDeviceToDevice); }
+        auto launch_i = [&](int i) { GemmParams q = p; q.A = as[i % NB]; q.C = cs[i % NB]; if (q.R) q.R = rs[i % NB]; launch_conv_patch(q, DT_F16, 0); };
+        for (int rep = 0; rep < NB; ++rep) launch_i(rep);
+        hipEventRecord(e0, 0);
+        for (int rep = 0; rep < 10; ++rep) launch_i(rep);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        for (int i = 0; i < NB; ++i) { hipFree(as[i]); hipFree(rs[i]); hipFree(cs[i]); }
+#else
         for (int rep = 0; rep < 3; ++rep) launch_conv_patch(p, DT_F16, 0);
         hipEventRecord(e0, 0);
         for (int rep = 0; rep < 10; ++rep) launch_conv_patch(p, DT_F16, 0);
         hipEventRecord(e1, 0);
+#endif
         hipDeviceSynchronize();
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
-        std::vector<unsigned long long> h((size_t)blocks * 10);
+        std::vector<unsigned long long> h((size_t)blocks * 18);
         hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
         auto med = [&](int slot) {
             std::vector<double> d;
@@ -58,6 +91,16 @@ int main() {
         printf("conv3x3 B=%d %dx%d Cin=%d Cout=%d res=%d: %.1f us per launch (stamped build, %.0f TF/s), %d blocks, %.0f units per block; block life (median) %.0f ticks = %.0f per unit\n", sh.B, sh.H,
                sh.H, sh.Cin, sh.Cout, sh.res, ms * 100.0, flops / (ms * 1e-4) / 1e12, blocks, units, life, life / units);
         const char* names[] = {"", "", "prologue", "unit top: requests + piece store", "ds_read + MFMA", "weight wait + ds_write", "barrier", "epilogue"};
+        {   // per wave: cycles between a barrier's release and the wave's arrival at the next one, per unit (median over blocks)
+            printf("    per-wave busy cycles per unit (waves 0-7):");
+            for (int w = 0; w < 8; ++w) {
+                std::vector<double> d;
+                for (int b = 0; b < blocks; ++b) d.push_back((double)h[(size_t)blocks * 10 + (size_t)b * 8 + w]);
+                std::sort(d.begin(), d.end());
+                printf(" %5.0f", d[d.size() / 2] / units);
+            }
+            printf("\n");
+        }
         for (int s = 2; s <= 7; ++s) printf("    %-36s %8.0f ticks %5.1f %% of life  (%5.0f per unit)\n", names[s], med(s), 100.0 * med(s) / life, med(s) / units);
         hipFree(a); hipFree(w); hipFree(c); hipFree(r); hipFree(bias);
     }

@@ -8,6 +8,14 @@
 #include <cstring>
 #include <vector>
 
+// random fp16 operands in [-0.5, 0.5) (constant fills run 10-15 % faster than real data: the clock follows the matrix pipe's power draw)
+static void fill_random(void* p, size_t bytes, unsigned seed) {
+    std::vector<uint16_t> h(bytes / 2);
+    unsigned x = seed;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; const float f = ((int)(x >> 9 & 0x3fff) - 8192) / 16384.0f; _Float16 hf = (_Float16)f; v = *reinterpret_cast<uint16_t*>(&hf); }
+    hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice);
+}
+
 int main() {
     struct Shape { int M, K, N, res, tile; };
     const Shape shapes[] = {{16384, 640, 640, 0, 0}, {16384, 640, 640, 0, 1}, {16384, 640, 640, 1, 1}, {4096, 1280, 1280, 1, 0}, {16384, 2560, 640, 1, 1}, {16384, 640, 1920, 0, 1}, {16384, 5120, 2560, 0, 1}, {8192, 8192, 8192, 0, 1}};
@@ -21,7 +29,7 @@ int main() {
         float* bias;
         hipMalloc(&a, (size_t)sh.M * sh.K * 2); hipMalloc(&w, (size_t)sh.N * sh.K * 2); hipMalloc(&c, (size_t)sh.M * sh.N * 2); hipMalloc(&r, (size_t)sh.M * sh.N * 2);
         hipMalloc(&bias, sh.N * 4);
-        hipMemset(a, 0x11, (size_t)sh.M * sh.K * 2); hipMemset(w, 0x12, (size_t)sh.N * sh.K * 2); hipMemset(r, 0x13, (size_t)sh.M * sh.N * 2); hipMemset(bias, 0, sh.N * 4);
+        fill_random(a, (size_t)sh.M * sh.K * 2, 1); fill_random(w, (size_t)sh.N * sh.K * 2, 2); fill_random(r, (size_t)sh.M * sh.N * 2, 3); hipMemset(bias, 0, sh.N * 4);
         GemmParams p;
         memset(&p, 0, sizeof(p));
         p.A = a; p.W = w; p.C = c; p.R = sh.res ? r : nullptr; p.bias = bias;
