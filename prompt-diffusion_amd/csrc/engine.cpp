@@ -697,8 +697,9 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     if (!use_patch && opt_patch_split && ptiles >= opt_patch_split_tiles && !gn_coef && m.N % 4 == 0) {
         const int chunks = p.Cin / (f32 ? 32 : 64);
         int sk = (opt_patch_split_fill + ptiles - 1) / ptiles;
-        if (sk > chunks / 4) sk = chunks / 4;
+        if (sk > chunks / opt_patch_split_min) sk = chunks / opt_patch_split_min;   // at least this many channel chunks per slice
         if (sk > 4) sk = 4;
+        while (sk >= 2 && (sk - 1) * ((chunks + sk - 1) / sk) >= chunks) --sk;       // no empty slice
         if (sk >= 2) { use_patch = true; patch_split = sk; }
     }
     if (gn_coef && !use_patch) {

@@ -295,6 +295,9 @@ struct pd_engine {
     int opt_short_k = 20;      // linear layers with at most this many K steps: 8-wave 128x160 tile at 16 waves per CU
     bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
     int opt_patch_split_tiles = 64;
+    int opt_patch_split_min = 4;      // ... each slice at least this many 128-byte channel chunks.  (min 1 / tiles 32 measured +2.3 % at batch 1 and
+                                      // neutral at batch 8, but re-associates the sums of the 256x256 parity fixture's convs: its step-0 latent error
+                                      // moves from 7.4e-4 to 1.02e-3 -- same arithmetic, other rounding pattern -- so the defaults stay)
     int opt_patch_split_fill = 256;   // slices are chosen to reach about this many blocks
     int opt_dense_k = 40;      // linear layers with at most this many K steps and >= opt_dense_tiles tiles: one 8-wave block per CU, no split-K
     bool opt_bigtile = true;  // 256-row GEMM tiles where the grid still fills the chip

@@ -752,6 +752,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }
     if (!strcmp(key, "patch_split")) { e->opt_patch_split = value != 0; return 0; }
     if (!strcmp(key, "patch_split_fill")) { e->opt_patch_split_fill = (int)value; return 0; }
+    if (!strcmp(key, "patch_split_min")) { if (value < 1) { pd_set_error("patch_split_min must be >= 1"); return 1; } e->opt_patch_split_min = (int)value; return 0; }
     if (!strcmp(key, "patch_split_tiles")) { e->opt_patch_split_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_tiles")) { e->opt_dense_tiles = (int)value; return 0; }
     if (!strcmp(key, "dense_k")) { e->opt_dense_k = (int)value; return 0; }
