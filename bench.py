@@ -283,7 +283,7 @@ def main():
             # fp16 MFMAs per 4 K-elements where f16 issues one per 8: a quarter of the fp16 rate
             peak = {"bf16": PEAK_BF16_TFLOPS, "f16": PEAK_BF16_TFLOPS, "f16x2": PEAK_BF16_TFLOPS / 4, "f32": PEAK_F32_TFLOPS}[args.precision]
             classes = {}
-            for name, k in (("igemm_kernel[conv3x3]", 0), ("igemm_kernel[linear/conv1x1]", 1), ("conv3x3_patch_kernel", 3),
+            for name, k in (("igemm_kernel[conv3x3]", 0), ("igemm+rgemm_kernel[linear/conv1x1]", 1), ("conv3x3_patch_kernel", 3),
                             ("attn_kernel", 2), ("st_tail_kernel", 4)):
                 ms, n, fl = eng.profile_read(k)
                 classes[name] = dict(ms=ms, launches=n, avg_us=1e3 * ms / max(n, 1), tflops=fl / max(ms, 1e-9) / 1e9)
@@ -305,7 +305,7 @@ def main():
             if rows:
                 by = sum(alg_bytes(r) for r in rows)
                 ms_s = sum(float(r["ms"]) for r in rows)
-                classes["igemm_kernel[linear, K<=1280: HBM view]"] = dict(
+                classes["igemm+rgemm_kernel[linear, K<=1280: HBM view]"] = dict(
                     ms=ms_s, launches=len(rows), avg_us=1e3 * ms_s / len(rows), algorithmic_gb_per_s=by / ms_s / 1e6,
                     frac_of_8_tb_s=by / ms_s / 1e6 / 8000.0)
             eng.set_option("profile", 0)
@@ -314,10 +314,10 @@ def main():
             # conv1x1 / generic conv3x3) and, since round 3, rgemm_kernel (gemm_ring.hip: the short-K linear layers).
             # Each bracket is ONE launch of that kernel (split-K finalize excluded), so avg_launch_us is comparable
             # with rocprofv3's call-weighted average over the igemm_kernel<...> rows (profiles/).
-            # (the HBM-view entry above is a sub-population of igemm_kernel[linear/conv1x1], not added again)
-            ms_g = classes["igemm_kernel[conv3x3]"]["ms"] + classes["igemm_kernel[linear/conv1x1]"]["ms"]
-            n_g = classes["igemm_kernel[conv3x3]"]["launches"] + classes["igemm_kernel[linear/conv1x1]"]["launches"]
-            fl_g = sum(classes[k]["tflops"] * classes[k]["ms"] for k in ("igemm_kernel[conv3x3]", "igemm_kernel[linear/conv1x1]"))
+            # (the HBM-view entry above is a sub-population of igemm+rgemm_kernel[linear/conv1x1], not added again)
+            ms_g = classes["igemm_kernel[conv3x3]"]["ms"] + classes["igemm+rgemm_kernel[linear/conv1x1]"]["ms"]
+            n_g = classes["igemm_kernel[conv3x3]"]["launches"] + classes["igemm+rgemm_kernel[linear/conv1x1]"]["launches"]
+            fl_g = sum(classes[k]["tflops"] * classes[k]["ms"] for k in ("igemm_kernel[conv3x3]", "igemm+rgemm_kernel[linear/conv1x1]"))
             achieved = fl_g / max(ms_g, 1e-9)
             # HBM traffic per launch: PMC counters cannot be collected from inside this process; tools/final_measure.sh runs
             # the FETCH_SIZE / WRITE_SIZE passes on this same command line (50-step workload) and commits the summary
