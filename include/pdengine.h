@@ -206,12 +206,20 @@ int pd_wait_stream(pd_engine* e, void* producer);
  *   "sd3_fp8" (SD3 path, 2-byte modes: 0 off; 1 the projections fed by an AdaLN output -- q/k/v of both streams, ff / ff_context
  *   net.0 -- take e4m3 operands with one scale per token and per output channel on the block-scaled K = 128 MFMA; 2 also the
  *   feed-forward-out projections, their input stored as e4m3 under a row bound; default 0),
- *   "attn_legacy" (single-buffered attention kernel, 0). */
+ *   "attn_legacy" (single-buffered attention kernel, 0),
+ *   "st_fuse" (320-channel SpatialTransformer blocks: st_front / st_tail fused kernels in the 2-byte modes, 1),
+ *   "ring" / "ring_tile" / "ring_geglu" (gemm_ring.hip: linear layers over 2-byte operands with at most that many 64-element K steps
+ *   take the persistent LDS-DMA ring GEMM, 80 / its tile -1 auto, 0 = 128x160, 1 = 256x160 / GEGLU projections too, 1; results are
+ *   bit-identical to the igemm tiles'), "slab_gn" (a ResBlock conv1 that runs split-K hands its fp32 slabs to the single-kernel
+ *   GroupNorm that reads them instead of running a finalize pass, 1; bit-identical), "patch_split_min" (patch-conv split-K: at
+ *   least this many 128-byte channel chunks per slice, 4). */
 int pd_set_option(pd_engine* e, const char* key, int64_t value);
-int64_t pd_get_stat(pd_engine* e, const char* key);  /* "workspace_bytes", "weight_bytes", "launches", "steps", "event_overhead_ns" */
+/* "workspace_bytes", "weight_bytes", "launches" (engine launches, split-K finalize passes not counted), "ring_launches" / "gn_from_slabs"
+ * (of which: gemm_ring.hip / GroupNorm fed by split-K slabs), "steps", "event_overhead_ns" */
+int64_t pd_get_stat(pd_engine* e, const char* key);
 /* Per-launch timing: while option "profile" is 1 the engine brackets every contraction launch with HIP
- * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel on a conv1x1/linear,
- * 2 = attention, 3 = conv3x3_patch_kernel, -1 = all.  One bracket = one launch (split-K finalize excluded).
+ * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel / rgemm_kernel on a conv1x1/linear,
+ * 2 = attention, 3 = conv3x3_patch_kernel, 4 = st_front / st_tail, -1 = all.  One bracket = one launch (split-K finalize excluded).
  * Returns summed device time, launch count and algorithmic FLOPs (2*M*N*K, logical channel counts).  The elapsed time of
  * a bracket around an empty one-block kernel, calibrated when "profile" is switched on (stat "event_overhead_ns"), is
  * taken off every bracket. */
