@@ -729,13 +729,17 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         }
         p.splitk = splitk;
         p.tile_cnt = (splitk > 1 && opt_splitk_fused) ? tile_cnt : nullptr;
+        // split-K conv3x3 with at least 1024 rows (the 8x8 level at batch 8): 256-row tiles halve the weight bytes each slice streams
+        // (every M tile reads the whole [160 x K / splitk] weight panel) when 256-row tiles x slices still give every CU a block
+        const bool sk256 = opt_splitk_big && splitk > 1 && !p.tile_cnt && m.taps == 9 && !f32 && p.M >= 1024 &&
+                           ((p.M + 255) / 256) * ((m.N + 159) / 160) * splitk >= 256;
         // the consumer sums the slabs itself (SlabDefer): plain bias / time-embedding epilogue only
         if (defer && defer->allow && splitk > 1 && !p.tile_cnt && p.slab && plain && act == 0 && scale == 1.f && !R && !VT && !ln_in && !ln_out && !m.geglu) {
             p.defer_finalize = 1;
             defer->active = true;
         }
         // 256-row tiles when they still give every CU a block (1 block of 8 waves per CU)
-        p.big_tile = (opt_bigtile && splitk == 1 && ((p.M + 255) / 256) * ((m.N + 159) / 160) >= 256) ? 1 : 0;
+        p.big_tile = ((opt_bigtile && splitk == 1 && ((p.M + 255) / 256) * ((m.N + 159) / 160) >= 256) || sk256) ? 1 : 0;
         if (dense8 && tiles < opt_splitk_tiles) p.big_tile = 2;
         // 256 x 320 tiles for linear layers that still give (almost) every CU a block
         {

@@ -283,6 +283,7 @@ struct pd_engine {
     int verbose = 0;
     bool opt_splitk_fused = false; // split-K sums + epilogue run in the last-arriving slice instead of a finalize kernel
     int opt_splitk_max = 8;
+    int opt_splitk_big = 0;       // split-K conv3x3 on 256 x 160 tiles where that still fills the chip (option "splitk_big")
     int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers

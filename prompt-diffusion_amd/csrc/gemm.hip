@@ -556,7 +556,9 @@ int launch_prec(const GemmParams& p, hipStream_t s, hipEvent_t mid) {
     constexpr bool F = prec_f32_storage(P);
     const bool conv = p.taps != 1;
     const bool af32 = !F && p.a_dt == DT_F32;          // 2-byte compute reading an fp32 A (converted while staging)
-    const int tile = p.splitk == 1 ? p.big_tile : 0;   // 0: 128x160, 1: 256x160, 2: 128x160 on 8 waves, 3: 256x320
+    // 0: 128x160, 1: 256x160, 2: 128x160 on 8 waves, 3: 256x320; split-K launches: 128x160, or 256x160 when the engine asks for it
+    // (plain slab stores work from any tile; the in-kernel finalize of option splitk_fused exists for the 128x160 tile only)
+    const int tile = p.splitk == 1 ? p.big_tile : ((p.big_tile == 1 && !p.tile_cnt) ? 1 : 0);
     if (p.act == 2) {
         if (conv || af32 || p.ln_stats || p.stats_out) return 1;
         // 256 x 320 on 4 x 2 waves (wave tile 64 x 160 = one GEGLU block): 14 fragment reads per 40 MFMAs.  Round 1 ran it on

@@ -737,6 +737,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "conv_patch2")) { e->opt_patch2 = value != 0; return 0; }
     if (!strcmp(key, "conv_patch2_tiles")) { e->opt_patch2_tiles = (int)value; return 0; }
     if (!strcmp(key, "splitk_fused")) { e->opt_splitk_fused = value != 0; return 0; }
+    if (!strcmp(key, "splitk_big")) { e->opt_splitk_big = (int)value; return 0; }
     if (!strcmp(key, "splitk_max")) { e->opt_splitk_max = (int)value; return 0; }
     if (!strcmp(key, "splitk_tiles")) { e->opt_splitk_tiles = (int)value; return 0; }
     if (!strcmp(key, "attn_legacy")) { e->opt_attn_legacy = value != 0; return 0; }
