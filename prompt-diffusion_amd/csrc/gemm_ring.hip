@@ -289,7 +289,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
                         for (int c = 0; c < 4; ++c) o[base + (size_t)c * p.vt_ld] = cvt16_rt(v[c], p.c_dt);
                     }
                 } else {
+#ifdef PD_KO_COALESCED   // diagnostic build: the same bytes, but every store instruction writes 512 contiguous bytes (wrong places)
+                    store4(p.C, min((size_t)(bm * ntiles + bn) * BM * BN + (size_t)((wave * MT + m) * NT + n) * 256, (size_t)p.M * p.N - 256) + lane * 4, p.c_dt, v);
+#else
                     store4(p.C, (size_t)gm * p.ldc + gn, p.c_dt, v);
+#endif
                 }
                 rs += (v[0] + v[1]) + (v[2] + v[3]);
                 rq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);

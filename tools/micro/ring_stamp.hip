@@ -1,7 +1,8 @@
 // Diagnostic build of gemm_ring.hip with s_memtime accumulators (wave 0 of every block): where do a block's cycles go?
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPD_STAMP -Iprompt-diffusion_amd/csrc tools/micro/ring_stamp.hip -o /tmp/ring_stamp && /tmp/ring_stamp
 // Read the SHARES, not the lengths: the stamps' fences forbid overlaps the product build has.
-// Without -DPD_STAMP: the product kernel, launch times only.  Knock-outs (timing only, results are garbage): -DPD_KO_DMA, -DPD_KO_DSREAD.
+// Without -DPD_STAMP: the product kernel, launch times only.  Knock-outs (timing only, results are garbage): -DPD_KO_DMA, -DPD_KO_DSREAD,
+// -DPD_KO_COALESCED (every store instruction writes 512 contiguous bytes).
 #include "../../prompt-diffusion_amd/csrc/gemm_ring.hip"
 #include <algorithm>
 #include <cstdio>
