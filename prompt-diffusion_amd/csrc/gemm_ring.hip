@@ -51,7 +51,11 @@ __device__ unsigned long long* g_ring_stamps = nullptr;
 
 // GG: the GEGLU epilogue (act == 2; weights pre-interleaved so that virtual columns [0, 80) of each 160-column block are x and
 // [80, 160) the gate): WN = 1, a wave owns whole blocks and writes x * gelu(gate), 80 columns per block.
-template <int P, int BM, int BN, int WM, int WN, int NS, bool GG = false>
+// PP ("ping-pong"): the waves of a block form two groups (waves >= WM * WN / 2 share their SIMDs one-to-one with the waves below) that
+// run half a K step apart: a step is a load phase (ring request, all fragment reads of the step) and an MFMA phase with a barrier
+// after each, and group 1 enters the loop one barrier late, so on every SIMD one wave issues MFMAs while its partner reads LDS and
+// issues LDS-DMA.  Same MFMA order per accumulator as the lockstep form (bit-identical results).
+template <int P, int BM, int BN, int WM, int WN, int NS, bool GG = false, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
     constexpr int NTHREADS = WM * WN * 64, RPI = NTHREADS / 8;   // RPI: tile rows one pass of all threads covers
     constexpr int A_IT = BM / RPI, B_IT = (BN + RPI - 1) / RPI, L = A_IT + B_IT;   // L: LDS-DMAs per wave and stage
@@ -158,15 +162,50 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
         }
     };
 
-    float2* sLn = reinterpret_cast<float2*>(smem + NS * STAGE);   // {mean, rstd} of the tile's rows (folded LayerNorm)
+    // PP: a step's fragments are all read in its load phase (both 32-element halves) and consumed in its MFMA phase
+    [[maybe_unused]] uint4 paf[PP ? 2 : 1][MT], pwf[PP ? 2 : 1][NT];
+    auto load_frags = [&](int slot) __attribute__((always_inline)) {
+        const char* sa = smem + slot * STAGE;
+        const char* sb = sa + BM * BKB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) paf[PP ? ks : 0][m] = *reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) pwf[PP ? ks : 0][n] = *reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, ks * 4 + fq));
+        }
+    };
+    auto mma_frags = [&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) mma<P>(pwf[PP ? ks : 0][n], paf[PP ? ks : 0][m], acc[n][m]);
+    };
+    auto pp_barrier = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // {mean, rstd} of the tile's rows (folded LayerNorm); PP: one buffer per tile parity (group 0 writes the next tile's while group 1
+    // still has the current tile's epilogue ahead of it)
+    float2* sLn = reinterpret_cast<float2*>(smem + NS * STAGE);
     [[maybe_unused]] unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_mma = 0, c_epi = 0;
     [[maybe_unused]] const unsigned long long t_begin = RT_NOW();
     setup(0);
     int issued = 0;
     for (; issued < NS - 1 && issued < G; ++issued) issue();
     int cslot = 0;
+    [[maybe_unused]] const int grp = wave >= WM * WN / 2 ? 1 : 0;
+    if constexpr (PP) {
+        wait_stage(issued - 1);   // stage 0 of every wave has landed
+        pp_barrier();
+        if (grp) pp_barrier();    // group 1 runs one phase behind
+    }
     for (int i = 0; i < nmy; ++i) {
         const int t = start + j + i * nbx, bm = t / ntiles, bn = t - bm * ntiles;
+        if constexpr (PP) sLn = reinterpret_cast<float2*>(smem + NS * STAGE) + (i & 1) * BM;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -176,6 +215,47 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
         // -- loads and stores retire through one in-order counter, and a read issued behind a store waits for that store
         f32x4 e_bias[NT], e_cs[NT];
         uint2 e_res[MT][NT];
+        if constexpr (PP) {
+            for (int kt = 0; kt < KT; ++kt) {
+                const int g = i * KT + kt;
+                // ---- load phase (the partner wave on this SIMD is in its MFMA phase)
+                if (kt == 0 && p.ln_stats && tid < BM) {   // (before the ring request: the compiler waits vmcnt(0) for these reads)
+                    const int gm = bm * BM + tid;
+                    float mean = 0.f, rstd = 0.f;
+                    if (gm < p.M) ln_row_stats(p, gm, mean, rstd);
+                    sLn[tid] = make_float2(mean, rstd);
+                }
+                // the step's fragment reads first (their latency runs under the DMA issue); stage g + NS - 1 goes into the slot of stage
+                // g - 1, which both groups have read before the barrier this phase began with
+                load_frags(cslot);
+                __builtin_amdgcn_sched_barrier(0);
+                if (issued < G) { issue(); ++issued; }
+                wait_stage(issued - 2 - g);   // this wave's pieces of stage g + 1 have landed (read from the next barrier-but-one on)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                pp_barrier();
+                // ---- MFMA phase
+                mma_frags(std::integral_constant<int, 0>{});
+                if (!GG && kt == KT - 1) {    // the epilogue's residual values: requested between the two halves of the tile's last MFMA phase,
+                    if (p.R) {                // into the registers of the first half's fragments, so that they travel under the second half
+                        // buffer loads: one lane offset + a scalar offset per (m, n) instead of 20 64-bit addresses held across the K loop; rows
+                        // past M read as zero, column groups past N read the next row (neither is stored)
+                        __builtin_amdgcn_sched_barrier(0);
+                        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.R), 0, (int)((size_t)p.M * p.ldr * 2), 0x00020000);
+                        const unsigned r_lane = ((unsigned)(bm * BM + wm * WTM + fr) * (unsigned)p.ldr + (unsigned)(bn * BN + wn * WTN + fq * 4)) * 2u;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                e_res[m][n] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rres, r_lane, (m * 16 * p.ldr + n * 16) * 2, 0));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                mma_frags(std::integral_constant<int, 1>{});
+                cslot = cslot + 1 == NS ? 0 : cslot + 1;
+                if (!(grp && g + 1 == G)) pp_barrier();   // (group 1 entered one barrier late and leaves one early)
+                else __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         for (int kt = 0; kt < KT; ++kt) {
             [[maybe_unused]] const unsigned long long t0 = RT_NOW();
             wait_stage(issued - 1 - (i * KT + kt));
@@ -319,12 +399,12 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
 #endif
 }
 
-template <int P, int BM, int BN, int WM, int WN, int NS, bool GG = false>
+template <int P, int BM, int BN, int WM, int WN, int NS, bool GG = false, bool PP = false>
 int launch_ring(const GemmParams& p, int ncu, hipStream_t s) {
-    constexpr int SMEM_BYTES = NS * (BM + BN) * BKB + BM * 8;
+    constexpr int SMEM_BYTES = NS * (BM + BN) * BKB + BM * 8 * (PP ? 2 : 1);
     static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
     static unsigned long long attr_done = 0;
-    auto kfn = rgemm_kernel<P, BM, BN, WM, WN, NS, GG>;
+    auto kfn = rgemm_kernel<P, BM, BN, WM, WN, NS, GG, PP>;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), SMEM_BYTES, &attr_done)) return 1;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN, nblk = mtiles * ntiles;
     if (p.stats_out && p.stats_parts != ntiles * WN) return 1;
@@ -341,7 +421,7 @@ bool ring_gemm_eligible(const GemmParams& p, int prec) {
     if (p.taps != 1 || p.a_dt != prec || p.a_silu || p.splitk > 1 || p.act == 4 || p.rowvec) return false;
     // GEGLU: whole 160-column blocks, nothing else in the epilogue
     if (p.act == 2 && (p.N % 160 || p.R || p.ln_stats || p.stats_out || p.vt_begin < p.N || p.out_scale != 1.f)) return false;
-    if (p.R && dt_size(p.r_dt) != 2) return false;   // the prefetched residual values are 2-byte
+    if (p.R && (dt_size(p.r_dt) != 2 || (unsigned long long)p.M * (unsigned)p.ldr * 2ull >= (1ull << 31))) return false;   // the prefetched residual values are 2-byte, 32-bit offsets
     if (p.gate || p.c_sample_rows || p.a_sample_rows || p.a_scale || p.c_scale || p.gn_coef) return false;
     if (p.K % 64 || p.K < 128 || p.K != p.Kpad || p.M < 1 || p.N % 4 || p.N < 4) return false;
     // 32-bit byte offsets inside each operand
@@ -362,6 +442,10 @@ int launch_ring_gemm(const GemmParams& p, int prec, int tile, hipStream_t s) {
     }
     if (p.act == 2) {   // 256 x 160 on 8 x 1 waves (a wave: 32 rows x one GEGLU block)
         return prec == DT_F16 ? launch_ring<DT_F16, 256, 160, 8, 1, 3, true>(p, ncu, s) : launch_ring<DT_BF16, 256, 160, 8, 1, 3, true>(p, ncu, s);
+    }
+    if (tile >= 2) {   // ping-pong forms: 2 = 128 x 160, 3 = 256 x 160
+        if (prec == DT_F16) return tile == 3 ? launch_ring<DT_F16, 256, 160, 4, 2, 3, false, true>(p, ncu, s) : launch_ring<DT_F16, 128, 160, 4, 2, 4, false, true>(p, ncu, s);
+        return tile == 3 ? launch_ring<DT_BF16, 256, 160, 4, 2, 3, false, true>(p, ncu, s) : launch_ring<DT_BF16, 128, 160, 4, 2, 4, false, true>(p, ncu, s);
     }
     if (prec == DT_F16) return tile ? launch_ring<DT_F16, 256, 160, 4, 2, 3>(p, ncu, s) : launch_ring<DT_F16, 128, 160, 4, 2, 4>(p, ncu, s);
     return tile ? launch_ring<DT_BF16, 256, 160, 4, 2, 3>(p, ncu, s) : launch_ring<DT_BF16, 128, 160, 4, 2, 4>(p, ncu, s);
