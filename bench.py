@@ -337,6 +337,17 @@ def main():
                     uj = json.load(f)
                 mfma_util = {k: v.get("mfma_util") for k, v in uj.get("by_kernel", {}).items()}
                 util_source = "profiles/" + util_files[-1] + ": " + uj.get("definition", "")
+            # trace-derived figures of the same families (tools/roofline_from_trace.py over the kernel trace of this command line)
+            trace = None
+            rl_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_roofline.json"))
+            if rl_files:
+                with open(os.path.join(ROOT, "profiles", rl_files[-1])) as f:
+                    tj2 = json.load(f)
+                fam = tj2.get("families", {}).get("igemm_kernel + rgemm_kernel")
+                if fam:
+                    trace = {"avg_launch_us": fam["trace_avg_us"], "tflops": fam["tflops"], "frac": fam["frac_of_2500"],
+                             "source": "profiles/" + rl_files[-1] + ": " + tj2.get("source", "")}
+            ov_us = eng.stat("event_overhead_ns") / 1e3
             result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel + rgemm_kernel (implicit-GEMM conv / linear: every instantiation of gemm.hip and gemm_ring.hip)",
                                   "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": traffic, "traffic_source": traffic_source,
@@ -344,7 +355,10 @@ def main():
                                   "algorithmic_bytes_per_launch": alg_per_launch,
                                   "traffic_over_algorithmic": (traffic / alg_per_launch) if traffic else None,
                                   "avg_launch_us": 1e3 * ms_g / max(n_g, 1), "launches": n_g,
-                                  "event_bracket_overhead_us": eng.stat("event_overhead_ns") / 1e3,
+                                  "avg_launch_us_raw_bracket": 1e3 * ms_g / max(n_g, 1) + ov_us,
+                                  "event_bracket_overhead_us": ov_us,
+                                  "event_bracket_calibration": "back-to-back event pairs with nothing between them",
+                                  "trace": trace,
                                   "flop_per_launch": 1e9 * fl_g / max(n_g, 1), "device_ms_per_pass": ms_g, "by_kernel": classes}
         # first-stage decode of the 8 latents, outside the metric's timed region: reported for context
         try:

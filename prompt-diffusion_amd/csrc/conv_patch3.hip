@@ -336,7 +336,8 @@ bool conv_patch3_eligible(const GemmParams& p, int prec) {
     if (p.gn_coef || p.a_dt != prec || p.Cin % BKE || p.K != 9 * p.Cin) return false;
     const unsigned long long a_bytes = (unsigned long long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * (unsigned)p.lda * 2ull;
     const unsigned long long w_bytes = (unsigned long long)p.N * (unsigned)p.Kpad * 2ull;
-    return a_bytes < (1ull << 32) && w_bytes < (1ull << 32);
+    const unsigned long long c_bytes = (unsigned long long)p.M * (unsigned)(p.ldc > p.ldr ? p.ldc : p.ldr) * 4ull;
+    return a_bytes < (1ull << 31) && w_bytes < (1ull << 32) && c_bytes < (1ull << 31);   // (buffer descriptors of conv_patch4.hip: 31-bit ranges)
 }
 
 int launch_conv_patch3(const GemmParams& p, int prec, hipStream_t s) {

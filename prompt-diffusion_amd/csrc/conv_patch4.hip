@@ -52,33 +52,29 @@ struct Geom4 {
     static constexpr int PROWS = PW * PW;
     static constexpr int P_PIECES = (PROWS + 7) / 8;       // 41 (plain) / 13 (upsampling) LDS-DMA pieces of 8 rows
     static constexpr int P_PER_WAVE = (P_PIECES + 3) / 4;  // 11 / 4: wave w requests pieces w + 4 j
-    static constexpr int P_BYTES = P_PIECES * 8 * ROWB;
+    static constexpr int P_BYTES = 4 * P_PER_WAVE * 8 * ROWB;   // whole pieces for every (wave, j): the ones past the patch are lanes out of range (zeros)
     static constexpr int SMEM = 2 * P_BYTES + NWB * W_TILE;
-    // piece j of the next chunk's patch is requested in the unit of tap tap_of(j): two per tap first, all of them by tap 6, so that the
+    // the next chunk's patch: taps 1-7 request per_tap(tap) <= 2 pieces per wave, the larger counts first (11 = 2 2 2 2 1 1 1); the
     // counted waits retire the last one in front of the barrier of tap 8
-    static constexpr int per_tap(int tap) { return tap < 7 ? (P_PER_WAVE + 6 - tap) / 7 : 0; }
+    static constexpr int per_tap(int tap) { return tap >= 1 && tap <= 7 ? (P_PER_WAVE + 7 - tap) / 7 : 0; }
     static constexpr int first_of(int tap) { int f = 0; for (int t = 0; t < tap; ++t) f += per_tap(t); return f; }
 };
 
-__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {   // gemm_ring.hip
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+// LDS-DMA of 64 x 16 B: wave-uniform 64-bit base + 32-bit lane offset -> LDS at M0 + 16 * lane.  M0 is written in the statement that
+// uses it and not restored: nothing else in this kernel reads M0 (no other LDS-DMA, no GWS, no movrel), and three scalar instructions
+// instead of five matter when ONE wave per SIMD issues everything.  The compiler does not see the request; waits are explicit.
+__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void bufds16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned lds_dst) {   // the buffer form: lanes out of range write zeros
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rs), "s"(soff), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ const char* uniform_ptr(const char* q) {   // provably wave-uniform for the "s" constraint
     const unsigned long long v = (unsigned long long)(uintptr_t)q;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return reinterpret_cast<const char*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
 }
-__device__ __forceinline__ void wait_vm_n(int n) {   // n is wave-uniform and small
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    }
-}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void w4_barrier() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
@@ -86,6 +82,16 @@ __device__ __forceinline__ void w4_barrier() {
 }
 
 struct Frag4 { uint4 a[2]; uint4 w[5]; };   // one 16-channel K step: 2 pixel tiles, 5 channel tiles
+
+// Diagnostic build only (tools/micro/conv_w4_stamp.hip compiles this file with -DPD_STAMP): where wave 0 of every block spends its cycles.
+#ifdef PD_STAMP
+__device__ unsigned long long* g_w4_stamps = nullptr;
+#define WT_NOW() ([]() { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); return t_; }())
+#define WT_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define WT_NOW() 0ull
+#define WT_ADD(acc, a, b) do { } while (0)
+#endif
 
 template <int P, int UPS>
 __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
         c0 = blockIdx.y * per;
         nchunks = min(chunks_all, c0 + per) - c0;
     }
-    const int U = nchunks * 9;
+    [[maybe_unused]] const int U = nchunks * 9;
 
     // ---- this lane's LDS-DMA sources.  A piece is 8 LDS rows; lane l writes row 8 * piece + (l >> 3), slot l & 7, and fetches the
     // logical chunk that the swizzle keeps in that slot.
@@ -151,25 +157,17 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
 
     const char* Wb = reinterpret_cast<const char*>(p.W);
 
+    // wave-uniform LDS destinations of this wave's pieces (piece wave + 4 j of a weight slot / a patch buffer)
+    const unsigned wdst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + 2 * G::P_BYTES + (unsigned)wave * 8 * ROWB));
+    const unsigned pdst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)wave * 8 * ROWB));
     auto issue_w = [&](auto J, const char* base, int slot) __attribute__((always_inline)) {   // piece wave + 4 j of a weight tile -> ring slot
         constexpr int j = decltype(J)::value;
-        const unsigned dst = lds0 + 2 * G::P_BYTES + (unsigned)slot * W_TILE + (unsigned)(wave + 4 * j) * 8 * ROWB;
-        glds16(base, w_off[j], (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+        glds16(base, w_off[j], wdst0 + (unsigned)slot * W_TILE + j * 4 * 8 * ROWB);
     };
     auto w_base = [&](int c, int tap) __attribute__((always_inline)) { return uniform_ptr(Wb + ((size_t)tap * p.Cin + (size_t)c * BKE) * 2); };
-    auto issue_p = [&](auto J, int c, int buf) __attribute__((always_inline)) -> int {        // piece wave + 4 j of chunk c's patch; 1 if requested
+    auto issue_p = [&](auto J, int c, int buf) __attribute__((always_inline)) {                // piece wave + 4 j of chunk c's patch
         constexpr int j = decltype(J)::value;
-        if constexpr (j < G::P_PER_WAVE) {
-            if (wave + 4 * j < G::P_PIECES) {
-                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)buf * G::P_BYTES + (unsigned)(wave + 4 * j) * 8 * ROWB));
-                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(c * BKE * 2);
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(p_off[j]), "s"(rsA), "s"(soff), "s"(dst) : "memory");
-                return 1;
-            }
-        }
-        return 0;
+        if constexpr (j < G::P_PER_WAVE) bufds16(rsA, p_off[j], (unsigned)(c * BKE * 2), pdst0 + (unsigned)buf * G::P_BYTES + j * 4 * 8 * ROWB);
     };
 
     f32x16 acc[5][2];   // [channel tile][pixel tile]: lane = pixel l31 of the tile, register r = channel (r & 3) + 8 (r >> 2) + 4 lh
@@ -181,14 +179,14 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
 
     // ---- prologue: patch c0 and the weight tiles of units 0 and 1
-    static_for<G::P_PER_WAVE>([&](auto J) { (void)issue_p(J, c0, 0); });
+    static_for<G::P_PER_WAVE>([&](auto J) { issue_p(J, c0, 0); });
     {
         const char* b0 = w_base(c0, 0);
         static_for<5>([&](auto J) { issue_w(J, b0, 0); });
         const char* b1 = w_base(c0, 1);
         static_for<5>([&](auto J) { issue_w(J, b1, 1); });
     }
-    wait_vm_n(0);
+    wait_vm<0>();
     w4_barrier();
 
     // One K step in 10 slots of one MFMA each (MFMA i = channel tile i / 2 x pixel tile i % 2 of the step's fragments), each followed by
@@ -228,54 +226,63 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+    const char* wbase = nullptr;      // source of the weight tile being requested (set behind each barrier)
     ReadCtx rc = read_ctx(I0{}, 0);   // of the unit whose fragments are being read: recomputed behind each barrier
     static_for<7>([&](auto IC) { read_one(IC, I0{}, rc, f0); });
     static_for<7>([&](auto IC) { read_one(IC, I1{}, rc, f1); });
 
-    int p_pending = 0;   // patch pieces requested behind the previous unit's barrier (they stay in flight across this unit's wait)
+    [[maybe_unused]] unsigned long long c_wait = 0, c_bar = 0;
+    [[maybe_unused]] const unsigned long long t_begin = WT_NOW();
+#ifdef PD_STAMP
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    // The steady state has NO branches (with one wave per SIMD every taken branch is ~15 cycles in which the matrix pipe idles: the first
+    // build, with its "last unit?" tests around the reads and requests, lost 500 cycles per unit to them): reads past the slice's end
+    // fetch stale LDS bytes that nothing uses, requests past it repeat the last tile / chunk into buffers nobody reads any more, and
+    // everything is drained in front of the epilogue.
+    const int last_c = c0 + nchunks - 1;
     auto step = [&](auto TAPC, auto SC, int lc) __attribute__((always_inline)) {
         constexpr int tap = decltype(TAPC)::value, s = decltype(SC)::value;
         constexpr int tl = tap * 4 + s;   // step index inside the chunk
         const int c = c0 + lc;
-        const int u = lc * 9 + tap;
-        const bool nextc = lc + 1 < nchunks;
         if constexpr (s == 2) {
-            // B_u: tile u + 1 (and the patch pieces requested before the previous barrier) have landed for every wave
-            wait_vm_n(u + 1 < U ? p_pending : 0);
+            // B_u: tile u + 1 and the previous unit's patch pieces have landed for every wave; this unit's own patch pieces (requested in
+            // steps 0 and 1, the youngest entries of the queue) stay in flight
+            [[maybe_unused]] const unsigned long long t0 = WT_NOW();
+            wait_vm<G::per_tap(tap)>();
+            [[maybe_unused]] const unsigned long long t1 = WT_NOW();
             w4_barrier();
+            [[maybe_unused]] const unsigned long long t2 = WT_NOW();
+            WT_ADD(c_wait, t0, t1); WT_ADD(c_bar, t1, t2);
         }
         // step t + 2: (tap2, s2) of this chunk or the next
         constexpr int s2 = (s + 2) % 4, tap2 = (tap + (s + 2) / 4) % 9;
         constexpr bool wrap = tap + (s + 2) / 4 >= 9;
-        const bool do_read = !(wrap && !nextc);
         if constexpr (s == 2) rc = read_ctx(std::integral_constant<int, tap2>{}, wrap ? lc + 1 : lc);   // steps t + 2 ... t + 5 are unit u + 1
         Frag4& fn = FS(std::integral_constant<int, tl + 2>{});
         const Frag4& fc = FS(std::integral_constant<int, tl>{});
-        const bool do_w = u + 2 < U;
-        const int t2 = tap + 2;
-        const char* wb = (s >= 2 && do_w) ? w_base(t2 >= 9 ? c + 1 : c, t2 >= 9 ? t2 - 9 : t2) : nullptr;
-        int np = 0;
+        constexpr int t2 = tap + 2;
+        const char* wb = nullptr;
+        if constexpr (s == 2) wbase = w_base(min(t2 >= 9 ? c + 1 : c, last_c), t2 >= 9 ? t2 - 9 : t2);   // tile u + 2 (past the end: a valid tile, unused)
+        if constexpr (s >= 2) wb = wbase;
+        const int cn = min(c + 1, last_c);
         __builtin_amdgcn_sched_barrier(0);
         static_for<10>([&](auto IC) {
             constexpr int i = decltype(IC)::value;
             mma32<P>(fc.w[i / 2], fc.a[i % 2], acc[i / 2][i % 2]);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i < 7) {
-                if (do_read) read_one(IC, std::integral_constant<int, s2>{}, rc, fn);
-            } else if constexpr (s == 2) {
-                // behind B_u: weight tile u + 2 into the slot of unit u - 1 (3 pieces here, 2 in the next step)
-                if (do_w) issue_w(std::integral_constant<int, i - 7>{}, wb, t2 % NWB);
-            } else if constexpr (s == 3) {
-                if constexpr (i < 9) {
-                    if (do_w) issue_w(std::integral_constant<int, i - 4>{}, wb, t2 % NWB);
-                } else if (nextc) {   // ... then the next chunk's patch pieces of this tap (the youngest entries of the queue)
-                    constexpr int first = G::first_of(tap), cnt = G::per_tap(tap);
-                    static_for<cnt>([&](auto J) { np += issue_p(std::integral_constant<int, first + decltype(J)::value>{}, c + 1, (lc + 1) & 1); });
-                }
+            if constexpr (i < 7) read_one(IC, std::integral_constant<int, s2>{}, rc, fn);
+            // LDS-DMA requests.  Behind B_u (steps 2 and 3): the 5 pieces of weight tile u + 2, into the slot of unit u - 1, one every
+            // fourth MFMA.  Steps 0 and 1 of taps 1-7: the next chunk's patch pieces of this tap (behind B of tap 0 every wave has the
+            // previous chunk's last fragments in registers).
+            if constexpr (s >= 2) {
+                constexpr int slot = 10 * (s - 2) + i;
+                if constexpr (slot % 4 == 1) issue_w(std::integral_constant<int, slot / 4>{}, wb, t2 % NWB);
+            } else if constexpr (i == 8 && s < G::per_tap(tap)) {
+                issue_p(std::integral_constant<int, G::first_of(tap) + s>{}, cn, (lc + 1) & 1);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (s == 3) p_pending = np;
     };
     auto unit = [&](auto TAPC, int lc) __attribute__((always_inline)) {
         step(TAPC, std::integral_constant<int, 0>{}, lc);
@@ -295,25 +302,96 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
         unit(std::integral_constant<int, 8>{}, lc);
     }
 
+    wait_vm<0>();   // the requests past the slice's end have landed: no LDS-DMA may outlive the block
     // ---- epilogue (split-K: this slice's fp32 partial goes to its slab; splitk_finalize_kernel or the consumer sums and finishes)
+    [[maybe_unused]] const unsigned long long t_epi = WT_NOW();
     float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.slab) + (size_t)blockIdx.y * p.M * p.N : nullptr;
     // this lane's two pixels and their 20 groups of 4 consecutive channels each: tile n, group g -> channel 32 n + 8 g + 4 lh
+    const bool fast = !slab && p.act == 0 && p.c_dt == P && (!p.R || p.r_dt == P) && !p.ln_stats;
+    if (fast) {
+        // pd_mma.h epilogue4's arithmetic -- (acc + bias + time-embedding row) * scale + residual -- with EVERY read issued before the first
+        // use: written as 40 calls of epilogue4_value, hipcc waits vmcnt(0) behind each optional read (120 dependent round trips per
+        // lane: 54 k cycles per tile on this kernel).  Absent operands read a valid address and are not added (select, no branch).
+        const bool hb = p.bias != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+        // buffer loads / stores: one lane offset per operand + compile-time offsets per channel group (40 64-bit addresses per operand
+        // would not fit beside the accumulators); channel groups past N read zeros or a neighbour row and are not stored
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb ? p.bias : reinterpret_cast<const float*>(p.W)), 0, p.N * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(hv ? p.rowvec + (size_t)sample * p.rowvec_stride : reinterpret_cast<const float*>(p.W)), 0, p.N * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hr ? p.R : p.C), 0, (int)((size_t)p.M * (hr ? p.ldr : p.ldc) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rc_ = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((size_t)p.M * p.ldc * 2), 0x00020000);
+        const int ldr = hr ? p.ldr : 0;
+        const int gn0 = bn * BN + lh * 4;   // + 32 n + 8 g
+        unsigned ro[2], co[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int oy = y0 + 4 * wave + 2 * m + (l31 >> 4), ox = x0 + (l31 & 15);
-        const int tok = oy * p.Wout + ox;
-        const int gm = sample * p.rows_per_sample + tok;
-        if (!slab) {   // pass 1: every read of the epilogue before the first store (pd_mma.h epilogue4_value)
-#pragma unroll
-            for (int n = 0; n < 5; ++n)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int gn = min(bn * BN + n * 32 + g * 8 + lh * 4, p.N - 4);
-                    const f32x4 v = epilogue4_value(p, gm, gn, sample, f32x4{acc[n][m][4 * g], acc[n][m][4 * g + 1], acc[n][m][4 * g + 2], acc[n][m][4 * g + 3]});
-                    acc[n][m][4 * g] = v[0]; acc[n][m][4 * g + 1] = v[1]; acc[n][m][4 * g + 2] = v[2]; acc[n][m][4 * g + 3] = v[3];
-                }
+        for (int m = 0; m < 2; ++m) {
+            const int tok = (y0 + 4 * wave + 2 * m + (l31 >> 4)) * p.Wout + x0 + (l31 & 15);
+            const unsigned gm = (unsigned)(sample * p.rows_per_sample + tok);
+            ro[m] = (gm * (unsigned)ldr + (unsigned)gn0) * 2u;
+            co[m] = (gm * (unsigned)p.ldc + (unsigned)gn0) * 2u;
         }
-    }
+        // two halves of 10 channel groups (both pixels): the second half's bias / time-embedding rows are requested once the first half's
+        // results are packed, still in front of the first store -- 120 + 40 instead of 240 operand registers
+        f32x4 eb[10], ev[10];
+        uint2 er[2][20], out[2][10];
+        auto load_vec = [&](auto H) __attribute__((always_inline)) {
+            constexpr int h = decltype(H)::value;
+            static_for<10>([&](auto Q) {
+                constexpr int qq = 10 * h + decltype(Q)::value, q = decltype(Q)::value;
+                constexpr int coff = ((qq >> 2) * 32 + (qq & 3) * 8) * 4;
+                eb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)gn0 * 4u, coff, 0));
+                ev[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)gn0 * 4u, coff, 0));
+            });
+        };
+        auto value = [&](int m, int qq) __attribute__((always_inline)) -> uint2 {   // qq: 0..19; eb / ev hold its half
+            const int n = qq >> 2, g = qq & 3, q = qq % 10;
+            f32x4 v = f32x4{acc[n][m][4 * g], acc[n][m][4 * g + 1], acc[n][m][4 * g + 2], acc[n][m][4 * g + 3]};
+            const f32x4 vb = v + eb[q];
+            v = hb ? vb : v;
+            const f32x4 vv = v + ev[q];
+            v = hv ? vv : v;
+            v *= p.out_scale;
+            float r0, r1, r2, r3;
+            unpack2<P>(er[m][qq].x, r0, r1); unpack2<P>(er[m][qq].y, r2, r3);
+            const f32x4 vr = v + f32x4{r0, r1, r2, r3};
+            v = hr ? vr : v;
+            uint2 o;
+            o.x = pack2<P>(v[0], v[1]); o.y = pack2<P>(v[2], v[3]);
+            return o;
+        };
+        auto store_half = [&](auto H) __attribute__((always_inline)) {
+            constexpr int h = decltype(H)::value;
+            static_for<2>([&](auto MC) {
+                constexpr int m = decltype(MC)::value;
+                static_for<10>([&](auto Q) {
+                    constexpr int qq = 10 * h + decltype(Q)::value, q = decltype(Q)::value;
+                    constexpr int coff = (qq >> 2) * 32 + (qq & 3) * 8;
+                    if (gn0 + coff < p.N) { typedef unsigned int u32x2_t __attribute__((__vector_size__(8))); __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, out[m][q]), rc_, co[m], coff * 2, 0); }
+                });
+            });
+        };
+        load_vec(std::integral_constant<int, 0>{});
+        static_for<2>([&](auto MC) {
+            constexpr int m = decltype(MC)::value;
+            static_for<20>([&](auto Q) {
+                constexpr int qq = decltype(Q)::value;
+                er[m][qq] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rr, ro[m], ((qq >> 2) * 32 + (qq & 3) * 8) * 2, 0));
+            });
+        });
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 10; ++q) out[m][q] = value(m, q);
+        __builtin_amdgcn_sched_barrier(0);
+        load_vec(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        store_half(std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 10; ++q) out[m][q] = value(m, 10 + q);
+        store_half(std::integral_constant<int, 1>{});
+    } else {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int oy = y0 + 4 * wave + 2 * m + (l31 >> 4), ox = x0 + (l31 & 15);
@@ -325,11 +403,19 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
             for (int g = 0; g < 4; ++g) {
                 const int gn = bn * BN + n * 32 + g * 8 + lh * 4;
                 if (gn >= p.N) continue;
-                const f32x4 v = f32x4{acc[n][m][4 * g], acc[n][m][4 * g + 1], acc[n][m][4 * g + 2], acc[n][m][4 * g + 3]};
+                f32x4 v = f32x4{acc[n][m][4 * g], acc[n][m][4 * g + 1], acc[n][m][4 * g + 2], acc[n][m][4 * g + 3]};
                 if (slab) *reinterpret_cast<f32x4*>(slab + (size_t)gm * p.N + gn) = v;
-                else epilogue4_store(p, gm, gn, sample, tok, v);
+                else epilogue4(p, gm, gn, sample, tok, v);
             }
     }
+    }
+#ifdef PD_STAMP
+    if (tid == 0 && g_w4_stamps) {
+        unsigned long long* o = g_w4_stamps + (size_t)blockIdx.x * 8;
+        const unsigned long long t_end = WT_NOW();
+        o[0] = t_begin; o[1] = t_end; o[2] = c_wait; o[3] = c_bar; o[4] = t_end - t_epi; o[5] = (unsigned long long)U; o[6] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    }
+#endif
 }
 
 template <int P, int UPS>

@@ -762,6 +762,13 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         if (opt_ring > 0 && splitk == 1 && !fp8 && ktiles <= opt_ring && (p.act != 2 || opt_ring_geglu) && ring_gemm_eligible(p, P)) {
             use_ring = true;
             ring_tile = opt_ring_tile >= 0 ? opt_ring_tile : (((p.M + 255) / 256) * ((m.N + 159) / 160) >= 224 ? 1 : 0);
+            // ping-pong form (two wave groups half a K step apart; bit-identical): -10..-14 % on long reductions and -3..-5 % on one
+            // 256-row tile per CU; +6..+13 % where a block walks several short tiles (the groups' epilogues serialise) -- tools/micro/ring_pp.hip
+            if (opt_ring_pp && ring_tile < 2 && p.act != 2) {
+                const int bm = ring_tile ? 256 : 128;
+                const int nblk = ((p.M + bm - 1) / bm) * ((m.N + 159) / 160);
+                if (ktiles >= 40 || (ring_tile == 1 && nblk <= 256)) ring_tile += 2;
+            }
             p.big_tile = 0;
         }
         if (ln_out && splitk == 1 && !m.geglu && !VT) {   // this launch's own epilogue leaves the row statistics
@@ -812,7 +819,10 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     // second-generation (wave-specialised) patch kernel where it measures faster: many blocks per CU (its longer prologue
     // amortises) or the split-K 16x16 level; the 2-round 64x64 launches stay on the first generation (152 vs 142 us)
     const bool patch2 = use_patch && opt_patch2 && !f32 && !gn_coef && (patch_split > 1 || ptiles >= opt_patch2_tiles);
-    if (use_patch ? (patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream))
+    // fourth generation (4 waves per block, one per SIMD, 32x32x16 MFMAs, LDS-DMA operands): every unsplit 2-byte launch (-4..-8 % at
+    // batch 8, -17..-19 % at batch 1 against the faster of the first two; split-K launches tie and stay on the second)
+    const bool patch4 = use_patch && opt_patch4 && patch_split == 1 && p.act == 0 && conv_patch3_eligible(p, P);
+    if (use_patch ? (patch4 ? launch_conv_patch4(p, P, stream) : patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream))
                   : use_ring ? launch_ring_gemm(p, prec, ring_tile, stream) : launch_gemm(p, prec, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
         return 1;

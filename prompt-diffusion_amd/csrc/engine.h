@@ -292,6 +292,7 @@ struct pd_engine {
     bool opt_graph = false;    // pd_ddim_sample: capture the step loop in a hipGraph and replay it on later calls with the same arguments
     int opt_ring = 80;         // linear layers with at most this many K steps (0: off) take gemm_ring.hip's persistent LDS-DMA ring kernel
     int opt_ring_tile = -1;    // its tile: -1 auto, 0 = 128 x 160, 1 = 256 x 160
+    int opt_ring_pp = 1;       // its ping-pong form where it measures faster (long K, or one 256-row tile per CU)
     int opt_ring_geglu = 1;    // GEGLU projections too (256 x 160 on 8 x 1 waves)
     int opt_short_k = 20;      // linear layers with at most this many K steps: 8-wave 128x160 tile at 16 waves per CU
     bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
@@ -308,6 +309,7 @@ struct pd_engine {
     bool opt_gn_fuse = false;
     bool opt_patch = true;  // use the LDS-patch conv3x3 kernel where eligible
     bool opt_patch2 = true; // 2-byte modes: the wave-specialised second-generation patch kernel (conv_patch2.hip)
+    bool opt_patch4 = true; // 2-byte modes: the 4-wave patch kernel (conv_patch4.hip) for unsplit launches
     int opt_patch2_tiles = 768;   // ... for launches of at least this many blocks (and every split-K patch launch)
     long long launches = 0;
     long long gn_from_slabs = 0;   // GroupNorm launches that summed a split-K GEMM's slabs (stat "gn_from_slabs")

@@ -752,6 +752,8 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "ring_geglu")) { e->opt_ring_geglu = (int)value; return 0; }
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }
     if (!strcmp(key, "patch_split")) { e->opt_patch_split = value != 0; return 0; }
+    if (!strcmp(key, "ring_pp")) { e->opt_ring_pp = (int)value; return 0; }
+    if (!strcmp(key, "patch4")) { e->opt_patch4 = value != 0; return 0; }
     if (!strcmp(key, "patch_split_fill")) { e->opt_patch_split_fill = (int)value; return 0; }
     if (!strcmp(key, "patch_split_min")) { if (value < 1) { pd_set_error("patch_split_min must be >= 1"); return 1; } e->opt_patch_split_min = (int)value; return 0; }
     if (!strcmp(key, "patch_split_tiles")) { e->opt_patch_split_tiles = (int)value; return 0; }
@@ -767,15 +769,14 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
         e->prof.clear();
         e->ev_used = 0;
         if (e->profiling) {
-            // an event pair around a kernel reads the kernel PLUS the marker packets and the completion signal between them
-            // (~10 us here): calibrate that on a one-block kernel of ~1.5 us and take it off every bracket, so that the
-            // per-launch averages agree with a kernel trace
+            // an event pair around a kernel reads the kernel PLUS the marker packets between them: calibrate that on back-to-back event
+            // pairs with NOTHING between them and take it off every bracket.  (Round 3 calibrated on a pair around an empty launch and
+            // thereby subtracted that launch's own latency too: the per-launch averages came out 8 % under the kernel trace.)
             const int n = 64;
             std::vector<hipEvent_t> ev(2 * n);
             for (auto& x : ev) x = e->next_event();
             for (int i = 0; i < n; ++i) {
                 (void)hipEventRecord(ev[2 * i], e->stream);
-                (void)launch_fill_random(e->tile_cnt2, DT_F32, 0, 0.f, 0.f, 1, e->stream);   // n = 0: an empty one-block launch
                 (void)hipEventRecord(ev[2 * i + 1], e->stream);
             }
             (void)hipStreamSynchronize(e->stream);

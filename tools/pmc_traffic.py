@@ -4,7 +4,7 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per
 counters are in KB.  usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> "<command that was profiled>" """
 import collections, csv, glob, json, sys
 
-FAMILIES = ("igemm_kernel<", "rgemm_kernel<", "conv3x3_patch_kernel<", "conv3x3_patch2_kernel<", "attn2_kernel", "gn_apply_kernel<", "gn_stats_kernel<",
+FAMILIES = ("igemm_kernel<", "rgemm_kernel<", "conv3x3_patch_kernel<", "conv3x3_patch2_kernel<", "conv3x3_pp_kernel<", "conv3x3_w4_kernel<", "attn2_kernel", "gn_apply_kernel<", "gn_stats_kernel<",
             "gn_fused_kernel<", "layernorm_kernel<", "splitk_finalize_kernel", "concat_add_kernel", "st_tail_kernel<", "st_front_kernel<")
 
 

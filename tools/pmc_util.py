@@ -7,7 +7,7 @@ high on dispatches shorter than ~0.3 ms, so it is reported only for context.
 usage: python tools/pmc_util.py <pmc_dir> <out.json> "<command that was profiled>" """
 import collections, csv, glob, json, sys
 
-FAMILIES = ("igemm_kernel<", "rgemm_kernel<", "conv3x3_patch_kernel<", "conv3x3_patch2_kernel<", "attn2_kernel", "attn_kernel<", "st_tail_kernel<", "st_front_kernel<")
+FAMILIES = ("igemm_kernel<", "rgemm_kernel<", "conv3x3_patch_kernel<", "conv3x3_patch2_kernel<", "conv3x3_pp_kernel<", "conv3x3_w4_kernel<", "attn2_kernel", "attn_kernel<", "st_tail_kernel<", "st_front_kernel<")
 tot = collections.defaultdict(float)
 n = collections.Counter()
 dur = collections.defaultdict(float)
