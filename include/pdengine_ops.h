@@ -9,6 +9,7 @@
  *   pd_op_layernorm  nn.LayerNorm                                                  attention.py:263-265
  *   pd_op_attention  softmax(q k^T dh^-0.5) v, heads from the engine config        attention.py:171-193
  *   pd_op_spatial_transformer  one SpatialTransformer block of the loaded networks  attention.py:271-275,321-340
+ *   pd_op_time_embed timestep_embedding + the time_embed MLP of a loaded network    util.py:154-174, openaimodel.py:526-531
  */
 #ifndef PDENGINE_OPS_H
 #define PDENGINE_OPS_H
@@ -31,6 +32,10 @@ int pd_op_attention(pd_engine* e, const float* q, const float* k, const float* v
  * x [B, C, H, W], context [B, context_len, context_dim], y [B, C, H, W]; the same code path as a sampling step (2-byte modes at
  * 320 channels: self-attention + the fused tail kernel). */
 int pd_op_spatial_transformer(pd_engine* e, const char* prefix, const float* x, const float* context, int B, int H, int W, float* y);
+/* timestep_embedding(t, model_channels) (util.py:154-174: [cos | sin], max_period 10000, frequencies i / half) -> temb [n][model_channels],
+ * and time_embed(temb) = Linear -> SiLU -> Linear of the loaded network (net 0: UNet, 1: ControlNet; openaimodel.py:526-531) -> emb
+ * [n][4 * model_channels]; exactly what the sampler computes once per call for all its steps (pd_engine::compute_emb). */
+int pd_op_time_embed(pd_engine* e, int net, const int64_t* t, int n, float* temb, float* emb);
 #ifdef __cplusplus
 }
 #endif

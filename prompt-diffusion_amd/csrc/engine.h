@@ -10,6 +10,8 @@
 #include "pd_common.h"
 
 void pd_set_error(const char* fmt, ...);
+// timestep_embedding (util.py:154-174) of n timesteps on the host: [cos | sin] halves, fp32 like the reference
+void pd_host_timestep_embedding(const int64_t* t, int n, int dim, std::vector<float>& out);
 
 #define HIP_OK(expr)                                                                            \
     do {                                                                                        \

@@ -260,4 +260,28 @@ int pd_op_spatial_transformer(pd_engine* e, const char* prefix, const float* x, 
     return rc;
 }
 
+
+// timestep_embedding + time_embed MLP of a loaded network: the first two stages of pd_engine::compute_emb
+int pd_op_time_embed(pd_engine* e, int net, const int64_t* t, int n, float* temb, float* emb) {
+    if (!e || !t || n < 1 || (!temb && !emb)) { pd_set_error("null argument"); return 1; }
+    HIP_OK(hipSetDevice(e->device));
+    NetW& nw = net ? e->cnet : e->unet;
+    const int mc = e->cfg.model_channels, td = mc * 4;
+    std::vector<float> host;
+    pd_host_timestep_embedding(t, n, mc, host);
+    if (temb) memcpy(temb, host.data(), host.size() * sizeof(float));
+    if (!emb) return 0;
+    DevBuf a((size_t)n * mc * 4), b((size_t)n * td * 4), c((size_t)n * td * 4);
+    if (!a.p || !b.p || !c.p) { pd_set_error("allocation failed"); return 1; }
+    HIP_OK(hipMemcpy(a.p, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    Act te, e1, e2;
+    te.p = a.p; te.B = n; te.H = te.W = 1; te.C = mc; te.dt = DT_F32;
+    e1 = te; e1.p = b.p; e1.C = td;
+    e2 = e1; e2.p = c.p;
+    PD_TRY(e->gemm(nw.te0, te, e1, 1, 0, /*silu*/ 1, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
+    PD_TRY(e->gemm(nw.te2, e1, e2, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipMemcpy(emb, c.p, (size_t)n * td * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
 }  // extern "C"

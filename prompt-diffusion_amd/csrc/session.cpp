@@ -64,7 +64,7 @@ int pd_engine::make_schedule(int steps, float eta, std::vector<int64_t>& ts, std
 }
 
 // timestep_embedding, util.py:154-174: [cos, sin], freqs = exp(-ln(10000) * i / half) in float32
-static void host_timestep_embedding(const int64_t* t, int n, int dim, std::vector<float>& out) {
+void pd_host_timestep_embedding(const int64_t* t, int n, int dim, std::vector<float>& out) {
     const int half = dim / 2;
     out.assign((size_t)n * dim, 0.f);
     const float lg = -std::log(10000.0f);
@@ -85,7 +85,7 @@ int pd_engine::compute_emb(NetW& net, std::vector<float*>& tabs, const int64_t* 
     Act te = new_act(n, 1, 1, mc, DT_F32);
     if (!arena.dry) {
         std::vector<float> host;
-        host_timestep_embedding(t, n, mc, host);
+        pd_host_timestep_embedding(t, n, mc, host);
         HIP_OK(hipMemcpyAsync(te.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, stream));
         HIP_OK(hipStreamSynchronize(stream));
     }

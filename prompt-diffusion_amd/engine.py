@@ -137,6 +137,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_op_layernorm.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_int, fp]
     lib.pd_op_attention.argtypes = [C.c_void_p, fp, fp, fp] + [C.c_int] * 4 + [fp]
     lib.pd_op_spatial_transformer.argtypes = [C.c_void_p, C.c_char_p, fp, fp] + [C.c_int] * 3 + [fp]
+    lib.pd_op_time_embed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, fp, fp]
     if path is None:
         _lib = lib
     return lib
@@ -149,7 +150,7 @@ EXPORTS = [
     "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_wait_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_encode_ex", "pd_text_weights_missing",
     "pd_profile_read", "pd_profile_dump",
     "pd_sd3_configure", "pd_sd3_weights_missing", "pd_sd3_forward", "pd_sd3_control", "pd_sd3_sample", "pd_sd3_down_proj",
-    "pd_op_conv2d", "pd_op_linear", "pd_op_linear_fp8", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention", "pd_op_spatial_transformer",
+    "pd_op_conv2d", "pd_op_linear", "pd_op_linear_fp8", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention", "pd_op_spatial_transformer", "pd_op_time_embed",
 ]
 
 
@@ -570,6 +571,15 @@ class Engine:
         y = np.empty_like(x)
         self._check(self.lib.pd_op_layernorm(self._h, x.ctypes.data, g.ctypes.data, b.ctypes.data, rows, Cc, y.ctypes.data))
         return y
+
+    def op_time_embed(self, t, net: int = 0, want_emb: bool = True):
+        """(timestep_embedding(t, model_channels), time_embed(...)) of the loaded UNet (net 0) / ControlNet (net 1)."""
+        t = np.ascontiguousarray(t, np.int64)
+        mc = self.cfg.model_channels
+        temb = np.empty((t.size, mc), np.float32)
+        emb = np.empty((t.size, 4 * mc), np.float32) if want_emb else None
+        self._check(self.lib.pd_op_time_embed(self._h, int(net), t.ctypes.data, int(t.size), temb.ctypes.data, emb.ctypes.data if want_emb else None))
+        return temb, emb
 
     def op_attention(self, q, k, v):
         q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)

@@ -186,6 +186,89 @@ def run_net_case(tag, cfg, W, B, h, w, S, cfg_scale, eta, out):
           f"x_final |mean| {np.abs(res['samples']).mean():.4f}")
 
 
+def load_readme_images(size):
+    """The three PNGs of the README quick-start (README.md:37-40) at size x size, as uint8 HWC arrays: image_a = inverted house_line
+    (condition map of the support pair), image_b = house (its rgb image), query = inverted new_01."""
+    from PIL import Image, ImageOps
+    d = os.path.join(REF, "images_to_try")
+
+    def load(name, invert):
+        im = Image.open(os.path.join(d, name)).convert("RGB")
+        if invert:
+            im = ImageOps.invert(im)
+        return np.asarray(im.resize((size, size), Image.LANCZOS), dtype=np.uint8)
+    return load("house_line.png", True), load("house.png", False), load("new_01.png", True)
+
+
+def run_real_image_case(tag, cfg, W, S, cfg_scale, out):
+    """BASELINE config #1 as written: the house_line -> house support pair and the new_01 query at 256 x 256 (latent 32 x 32), bs 1,
+    S DDIM steps -- flat and saturated regions that the U(-1, 1) synthetic images never produce.  (L) convention: images in
+    [-1, 1], pair = [condition map (3), rgb image (3)].  The pixel arrays travel in the fixture (they are data)."""
+    h = w = 32
+    a_u8, b_u8, q_u8 = load_readme_images(8 * h)
+    to_m11 = lambda u8: (u8.astype(np.float32) / 127.5 - 1.0).transpose(2, 0, 1)[None]
+    model, cn, un = build_reference(cfg, W)
+    inp = W.synth_inputs(cfg, 1, h, w)
+    inp["pair"] = np.concatenate([to_m11(a_u8), to_m11(b_u8)], axis=1)
+    inp["query"] = to_m11(q_u8)
+    tt = {k: torch.from_numpy(v) for k, v in inp.items()}
+    cond = {"c_crossattn": [tt["ctx_cond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    uc = {"c_crossattn": [tt["ctx_uncond"]], "example_pair": [tt["pair"]], "query": [tt["query"]]}
+    sampler = make_sampler(model)
+    with torch.no_grad():
+        sampler.make_schedule(S, ddim_eta=0.0, verbose=False)
+        step = int(np.flip(sampler.ddim_timesteps)[0])
+        x_in = torch.cat([tt["x_T"]] * 2)
+        t_in = torch.full((2,), step, dtype=torch.long)
+        ctx = torch.cat([tt["ctx_uncond"], tt["ctx_cond"]])
+        eps = model.apply_model(x_in, t_in, {"c_crossattn": [ctx], "example_pair": [torch.cat([tt["pair"]] * 2)], "query": [torch.cat([tt["query"]] * 2)]})
+        samples, inter = sampler.sample(S, 1, (cfg.in_channels, h, w), cond, eta=0.0, x_T=tt["x_T"],
+                                        unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uc,
+                                        log_every_t=1, verbose=False)
+    np.savez_compressed(os.path.join(out, f"net_{tag}.npz"), B=1, h=h, w=w, S=S, cfg_scale=cfg_scale, eta=0.0, first_step=step,
+                        image_a_u8=a_u8, image_b_u8=b_u8, query_u8=q_u8, eps=t2n(eps),
+                        x_inter=np.stack([t2n(x) for x in inter["x_inter"]]), samples=t2n(samples))
+    print(f"[golden] net_{tag}: eps |mean| {np.abs(t2n(eps)).mean():.4f}, x_final |mean| {np.abs(t2n(samples)).mean():.4f}, "
+          f"flat pixels in the condition map {(a_u8 == a_u8[0, 0]).mean():.2f}")
+
+
+def run_dpm_solver_case(out):
+    """The multistep logic of the scheduler plug-in pinned by the reference's own DPM-Solver++ (ldm/models/diffusion/
+    dpm_solver/dpm_solver.py:319, :723): UniPC's order-2 predictor with B(h) = e^h - 1 is DPM-Solver++(2M) (solver_type 'dpmsolver').
+    An analytic epsilon model stands in for the network (the test evaluates the same closed form); everything in fp64."""
+    from ldm.models.diffusion.dpm_solver.dpm_solver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    ac = torch.from_numpy(np.cumprod(1.0 - betas))
+    ns = NoiseScheduleVP("discrete", alphas_cumprod=ac)
+    g = np.random.default_rng(7)
+    x_T = torch.from_numpy(g.standard_normal((2, 4, 8, 8)))
+    A = torch.from_numpy(g.standard_normal((4, 4)) * 0.3)
+
+    def eps_model(x, t_input):      # t_input = (t_continuous - 1/N) * 1000 (dpm_solver.py model_wrapper, discrete schedule)
+        tc = t_input / 1000.0 + 1.0 / 1000
+        s = (0.3 + 0.6 * tc).reshape(-1, 1, 1, 1)
+        return torch.tanh(torch.einsum("oc,bchw->bohw", A, x) * s) + 0.25 * x * (1.0 - s)
+    res = dict(x_T=x_T.numpy(), A=A.numpy())
+    for steps in (8, 5):
+        seen = []     # the sampler's x at every model evaluation = its state after each update (it never evaluates the last point)
+
+        def recording(x, t_input):
+            seen.append(x.detach().clone().numpy())
+            return eps_model(x, t_input)
+        solver = DPM_Solver(model_wrapper(recording, ns, model_type="noise", guidance_type="uncond"), ns, predict_x0=True)
+        x = solver.sample(x_T.clone(), steps=steps, t_start=1.0, t_end=1.0 / 1000, order=2, skip_type="time_uniform", method="multistep",
+                          lower_order_final=True, denoise_to_zero=False, solver_type="dpm_solver")
+        ts = solver.get_time_steps(skip_type="time_uniform", t_T=1.0, t_0=1.0 / 1000, N=steps, device=x_T.device)
+        assert len(seen) == steps
+        res[f"s{steps}_t"] = ts.numpy()
+        res[f"s{steps}_alpha"] = ns.marginal_alpha(ts).numpy()
+        res[f"s{steps}_sigma"] = ns.marginal_std(ts).numpy()
+        res[f"s{steps}_lambda"] = ns.marginal_lambda(ts).numpy()
+        res[f"s{steps}_x"] = np.stack(seen + [x.numpy()])
+        print(f"[golden] dpm_solver_2m steps {steps}: {len(seen) + 1} states, |x_final| mean {np.abs(x.numpy()).mean():.4f}")
+    np.savez_compressed(os.path.join(out, "dpm_solver_2m.npz"), **res)
+
+
 def run_traj_case(tag, cfg, W, B, h, w, S, cfg_scale, keep, out):
     """A whole DDIM trajectory of the reference sampler on the headline 50-step schedule: x_inter at the steps in `keep`
     (index into intermediates['x_inter'], 0 = x_T) plus the final sample.  Inputs come from the seeded recipe."""
@@ -481,6 +564,10 @@ def main():
     if want("sd15") and not args.skip_sd15:
         # BASELINE config #1: 256x256 (latent 32x32), 5 DDIM steps, bs=1, CFG
         run_net_case("sd15_b1_32x32_s5", W.SD15, W, B=1, h=32, w=32, S=5, cfg_scale=7.5, eta=0.0, out=out)
+    if only is not None and "sd15_house" in only:
+        run_real_image_case("sd15_b1_32x32_s5_house", W.SD15, W, S=5, cfg_scale=7.5, out=out)
+    if only is not None and "dpm" in only:
+        run_dpm_solver_case(out)
     # the headline 50-step schedule (BASELINE metric: per-step latent error at 50-step DDIM), pinned by the reference itself:
     # 256x256 with every latent, and one 512x512 image (BASELINE config #2's shape) with a subset of the latents
     if only is not None and "sd15_s50" in only:

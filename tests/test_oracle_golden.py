@@ -171,6 +171,30 @@ def test_sd15_config1_first_and_last_step(golden_dir):
         assert relerr(pred, g["pred_x0"][i + 1]) < 1e-4, i
 
 
+@pytest.mark.slow
+def test_sd15_config1_real_images_first_step(golden_dir):
+    """The same configuration on the README's example images (fixture net_sd15_b1_32x32_s5_house.npz: pixel arrays + the
+    reference's trajectory): one eps evaluation and the first DDIM step of the oracle against the reference's."""
+    path = os.path.join(golden_dir, "net_sd15_b1_32x32_s5_house.npz")
+    if not os.path.exists(path):
+        pytest.skip("real-image fixture not generated")
+    g = np.load(path)
+    cfg = W.SD15
+    to_m11 = lambda u8: (u8.astype(np.float32) / 127.5 - 1.0).transpose(2, 0, 1)[None]
+    inp = W.synth_inputs(cfg, 1, 32, 32)
+    pair = np.concatenate([to_m11(g["image_a_u8"]), to_m11(g["image_b_u8"])], axis=1)
+    query = to_m11(g["query_u8"])
+    sd = W.synth_state_dict(cfg)
+    lay = O.make_layouts(cfg, W)
+    cond = dict(c_crossattn=inp["ctx_cond"], example_pair=pair, query=query)
+    unc = dict(c_crossattn=inp["ctx_uncond"], example_pair=pair, query=query)
+    S = int(g["S"])
+    sched = O.make_schedule(S)
+    tr = np.flip(sched["ddim_timesteps"])
+    x_prev, _, _ = O.p_sample_ddim(sd, cfg, lay, sched, g["x_inter"][0], cond, unc, S - 1, int(tr[0]), float(g["cfg_scale"]))
+    assert relerr(x_prev, g["x_inter"][1]) < 1e-4
+
+
 @pytest.mark.parametrize("tag,cfg", [("tiny", W.TINY), ("sd15", W.SD15)])
 def test_vae_decoder_matches_reference(golden_dir, tag, cfg):
     """decode_first_stage = z/scale_factor -> post_quant_conv -> Decoder."""

@@ -125,3 +125,30 @@ def test_unipc_variants_run_and_close_on_the_data_prediction():
         t = sc.timesteps[-1]
         m = (x_in - np.sqrt(1 - ac[t]) * gaussian_eps(s, ac)(x_in, t)) / np.sqrt(ac[t])
         assert np.abs(x - m).max() < 1e-12
+
+
+def test_unipc_predictor_is_reference_dpm_solver_2m():
+    """The multistep logic (history, step ratios, warm-up order, lower-order final step) pinned by the REFERENCE tree's own
+    DPM-Solver++ (ldm/models/diffusion/dpm_solver/dpm_solver.py:319, :723-757, :1044-1070): UniPC's order-2 predictor with
+    B(h) = e^h - 1 ('bh2') and the corrector switched off is DPM-Solver++(2M), solver_type 'dpm_solver'.  The fixture
+    (tests/golden/make_golden.py --only dpm) ran the reference solver in fp64 on its own time-uniform grid with an analytic
+    epsilon model; here the plug-in runs on that grid's (alpha, sigma, lambda) with the same closed form."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dpm_solver_2m.npz"))
+    A = g["A"]
+
+    def eps_model(x, tc):   # the generator's closed form (it receives (t - 1/N) * 1000 from model_wrapper and undoes it)
+        s = 0.3 + 0.6 * tc
+        return np.tanh(np.einsum("oc,bchw->bohw", A, x) * s) + 0.25 * x * (1.0 - s)
+    for steps in (8, 5):
+        t = g[f"s{steps}_t"]
+        s = UniPCMultistepScheduler(disable_corrector=list(range(steps)))
+        s.set_timesteps(steps)
+        s._alpha, s._sigma, s._lambda = g[f"s{steps}_alpha"].copy(), g[f"s{steps}_sigma"].copy(), g[f"s{steps}_lambda"].copy()
+        x = g["x_T"].copy()
+        states = g[f"s{steps}_x"]
+        assert states.shape[0] == steps + 1
+        for i in range(steps):
+            np.testing.assert_allclose(x, states[i], rtol=0, atol=1e-12 * np.abs(states[i]).max())
+            x = s.step(eps_model(x, t[i]), int(s.timesteps[i]), x, return_dict=False)[0]
+        np.testing.assert_allclose(x, states[steps], rtol=0, atol=1e-12 * np.abs(states[steps]).max())
