@@ -29,17 +29,6 @@ constexpr int W_TILE = BN * ROWB;  // 20480
 constexpr int W_SLOTS = BN * 8;    // 16-byte chunks of a weight tile
 constexpr int W_ITERS = (W_SLOTS + NT - 1) / NT;  // 3 (last one half masked)
 
-// Diagnostic build only (tools/micro/conv_stamp.hip compiles this file with -DPD_STAMP): cycles wave 0 of every block spends in the
-// parts of a (chunk, tap) unit.  No stamp executes in the product build.
-#ifdef PD_STAMP
-__device__ unsigned long long* g_conv_stamps = nullptr;
-#define CT_NOW() ([]() { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); return t_; }())
-#define CT_ADD(acc, a, b) acc += (b) - (a)
-#else
-#define CT_NOW() 0ull
-#define CT_ADD(acc, a, b) do { } while (0)
-#endif
-
 // LDS rows are 128 B = 8 chunks of 16 B; a row's chunks are permuted by XORing bits 1-2 of the chunk index with (row >> 1) & 3.
 // A ds_read_b128 is served in four groups of 16 lanes, and a group of this kernel's fragment reads is 16 CONSECUTIVE rows of
 // which 8 read chunk c and 8 chunk c + 1 (c even); bit 0 is left alone, so the two halves never meet, and inside a half the four
@@ -204,8 +193,6 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     for (int n = 0; n < 5; ++n)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    [[maybe_unused]] unsigned long long c_top = 0, c_mma = 0, c_wst = 0, c_bar = 0, c_busy = 0;
-    [[maybe_unused]] const unsigned long long t_begin = CT_NOW();
 
     // ---- prologue: patch 0, weight tile of unit 0 in LDS; unit 1's weights in flight
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
@@ -240,7 +227,6 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
         // stored): hipcc's waitcnt insertion merges the counter state of both sides of a branch around a load, and a load
         // that "may not have been issued" turns the counted vmcnt(N) in front of store_w into vmcnt(0) -- the stall again.
         const int cn = nextc ? c + 1 : c;
-        [[maybe_unused]] const unsigned long long t0 = CT_NOW();
         load_w(tap + 1 >= 9 ? cn : c, tap + 1 >= 9 ? 0 : tap + 1);
         // next chunk's patch (two halves through the same registers) -> the other patch buffer, last read in chunk c-1
         {
@@ -253,7 +239,6 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
             if constexpr (tap == 6) { if (nextc) store_one(I4{}, nb, cn); }
             if constexpr (tap == 7) { if (nextc) store_one(I5{}, nb, cn); }
         }
-        [[maybe_unused]] const unsigned long long t1 = CT_NOW();
         const char* pa = sP + (lc & 1) * G::P_BYTES;
         const char* wa = sW + par * W_TILE;
         // keep the per-tap fragment addresses out of loop-invariant hoisting (they would otherwise live in
@@ -295,18 +280,10 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
                 for (int m = 0; m < 4; ++m) mma<P>(wf, af[m], acc[n][m]);
             }
         }
-#ifdef PD_STAMP
-        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[4][3]));   // the unit's MFMAs are issued before the stamp
-#endif
-        [[maybe_unused]] const unsigned long long t2 = CT_NOW();
         if (u + 1 < U) store_w(par ^ 1);
-        [[maybe_unused]] const unsigned long long t3 = CT_NOW();
         __syncthreads();
-        [[maybe_unused]] const unsigned long long t4 = CT_NOW();
-        CT_ADD(c_top, t0, t1); CT_ADD(c_mma, t1, t2); CT_ADD(c_wst, t2, t3); CT_ADD(c_bar, t3, t4);
-        CT_ADD(c_busy, t0, t3);
+
     };
-    [[maybe_unused]] const unsigned long long t_loop = CT_NOW();
     for (int c = 0; c < nchunks; ++c) {
         unit(std::integral_constant<int, 0>{}, c);
         unit(std::integral_constant<int, 1>{}, c);
@@ -320,7 +297,6 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
     }
 
     // ---- epilogue (split-K: this slice's fp32 partial goes to its slab; splitk_finalize_kernel sums and finishes)
-    [[maybe_unused]] const unsigned long long t_epi = CT_NOW();
     float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.slab) + (size_t)blockIdx.y * p.M * p.N : nullptr;
     if (!slab) {   // pass 1: every read of the epilogue before the first store (pd_mma.h epilogue4_value)
 #pragma unroll
@@ -346,14 +322,6 @@ __global__ __launch_bounds__(NT) void conv3x3_patch_kernel(GemmParams p) {
             else epilogue4_store(p, gm, gn, sample, tok, acc[n][m]);
         }
     }
-#ifdef PD_STAMP
-    if (lane == 0 && g_conv_stamps) g_conv_stamps[(size_t)gridDim.x * 10 + (size_t)blockIdx.x * 8 + wave] = c_busy;   // per wave: release -> arrival
-    if (threadIdx.x == 0 && g_conv_stamps) {
-        unsigned long long* o = g_conv_stamps + (size_t)blockIdx.x * 10;
-        const unsigned long long t_end = CT_NOW();
-        o[0] = t_begin; o[1] = t_end; o[2] = t_loop - t_begin; o[3] = c_top; o[4] = c_mma; o[5] = c_wst; o[6] = c_bar; o[7] = t_end - t_epi; o[8] = (unsigned long long)U;
-    }
-#endif
 }
 
 constexpr int COEF_BYTES_MAX = 24 * 1024;   // [Cin <= 3072][2] floats behind the staging buffers

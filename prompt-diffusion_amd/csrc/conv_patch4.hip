@@ -27,6 +27,7 @@
 
 #include "pd_common.h"
 #include "pd_mma.h"
+#include "pd_stamp.h"
 
 namespace {
 
@@ -83,15 +84,9 @@ __device__ __forceinline__ void w4_barrier() {
 
 struct Frag4 { uint4 a[2]; uint4 w[5]; };   // one 16-channel K step: 2 pixel tiles, 5 channel tiles
 
-// Diagnostic build only (tools/micro/conv_w4_stamp.hip compiles this file with -DPD_STAMP): where wave 0 of every block spends its cycles.
-#ifdef PD_STAMP
-__device__ unsigned long long* g_w4_stamps = nullptr;
-#define WT_NOW() ([]() { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); return t_; }())
-#define WT_ADD(acc, a, b) acc += (b) - (a)
-#else
-#define WT_NOW() 0ull
-#define WT_ADD(acc, a, b) do { } while (0)
-#endif
+// Diagnostic build only (tools/micro/conv_w4_stamp.hip compiles this file with -DPD_STAMP): where wave 0 of every block spends its cycles
+// (pd_stamp.h; nothing of it exists in the product build).
+PD_T_ONLY(__device__ unsigned long long* g_w4_stamps = nullptr;)
 
 template <int P, int UPS>
 __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
@@ -224,18 +219,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
         constexpr int r = decltype(T)::value % 3;
         if constexpr (r == 0) return f0; else if constexpr (r == 1) return f1; else return f2;
     };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     const char* wbase = nullptr;      // source of the weight tile being requested (set behind each barrier)
     ReadCtx rc = read_ctx(I0{}, 0);   // of the unit whose fragments are being read: recomputed behind each barrier
     static_for<7>([&](auto IC) { read_one(IC, I0{}, rc, f0); });
     static_for<7>([&](auto IC) { read_one(IC, I1{}, rc, f1); });
 
     [[maybe_unused]] unsigned long long c_wait = 0, c_bar = 0;
-    [[maybe_unused]] const unsigned long long t_begin = WT_NOW();
-#ifdef PD_STAMP
-    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
-#endif
+    [[maybe_unused]] const unsigned long long t_begin = PD_T_NOW();
+    PD_T_ONLY(const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();)
     // The steady state has NO branches (with one wave per SIMD every taken branch is ~15 cycles in which the matrix pipe idles: the first
     // build, with its "last unit?" tests around the reads and requests, lost 500 cycles per unit to them): reads past the slice's end
     // fetch stale LDS bytes that nothing uses, requests past it repeat the last tile / chunk into buffers nobody reads any more, and
@@ -248,12 +240,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
         if constexpr (s == 2) {
             // B_u: tile u + 1 and the previous unit's patch pieces have landed for every wave; this unit's own patch pieces (requested in
             // steps 0 and 1, the youngest entries of the queue) stay in flight
-            [[maybe_unused]] const unsigned long long t0 = WT_NOW();
+            [[maybe_unused]] const unsigned long long t0 = PD_T_NOW();
             wait_vm<G::per_tap(tap)>();
-            [[maybe_unused]] const unsigned long long t1 = WT_NOW();
+            [[maybe_unused]] const unsigned long long t1 = PD_T_NOW();
             w4_barrier();
-            [[maybe_unused]] const unsigned long long t2 = WT_NOW();
-            WT_ADD(c_wait, t0, t1); WT_ADD(c_bar, t1, t2);
+            [[maybe_unused]] const unsigned long long t2 = PD_T_NOW();
+            PD_T_ADD(c_wait, t0, t1); PD_T_ADD(c_bar, t1, t2);
         }
         // step t + 2: (tap2, s2) of this chunk or the next
         constexpr int s2 = (s + 2) % 4, tap2 = (tap + (s + 2) / 4) % 9;
@@ -304,7 +296,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
 
     wait_vm<0>();   // the requests past the slice's end have landed: no LDS-DMA may outlive the block
     // ---- epilogue (split-K: this slice's fp32 partial goes to its slab; splitk_finalize_kernel or the consumer sums and finishes)
-    [[maybe_unused]] const unsigned long long t_epi = WT_NOW();
+    [[maybe_unused]] const unsigned long long t_epi = PD_T_NOW();
     float* slab = p.splitk > 1 ? reinterpret_cast<float*>(p.slab) + (size_t)blockIdx.y * p.M * p.N : nullptr;
     // this lane's two pixels and their 20 groups of 4 consecutive channels each: tile n, group g -> channel 32 n + 8 g + 4 lh
     const bool fast = !slab && p.act == 0 && p.c_dt == P && (!p.R || p.r_dt == P) && !p.ln_stats;
@@ -409,13 +401,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
             }
     }
     }
-#ifdef PD_STAMP
-    if (tid == 0 && g_w4_stamps) {
+    PD_T_ONLY(if (tid == 0 && g_w4_stamps) {
         unsigned long long* o = g_w4_stamps + (size_t)blockIdx.x * 8;
-        const unsigned long long t_end = WT_NOW();
+        const unsigned long long t_end = PD_T_NOW();
         o[0] = t_begin; o[1] = t_end; o[2] = c_wait; o[3] = c_bar; o[4] = t_end - t_epi; o[5] = (unsigned long long)U; o[6] = __builtin_amdgcn_s_memrealtime() - r_begin;
-    }
-#endif
+    })
 }
 
 template <int P, int UPS>
@@ -433,8 +423,19 @@ int launch_w4(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+// shapes conv_patch_tiles() accepts, 2-byte compute types, no fused GroupNorm, plain epilogue; 31-bit byte ranges inside each operand
+// (buffer descriptors) and 32-bit weight offsets
+bool conv_patch4_eligible(const GemmParams& p, int prec) {
+    if (prec != DT_F16 && prec != DT_BF16) return false;
+    if (p.gn_coef || p.a_dt != prec || p.Cin % BKE || p.K != 9 * p.Cin || p.act != 0) return false;
+    const unsigned long long a_bytes = (unsigned long long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * (unsigned)p.lda * 2ull;
+    const unsigned long long w_bytes = (unsigned long long)p.N * (unsigned)p.Kpad * 2ull;
+    const unsigned long long c_bytes = (unsigned long long)p.M * (unsigned)(p.ldc > p.ldr ? p.ldc : p.ldr) * 4ull;
+    return a_bytes < (1ull << 31) && w_bytes < (1ull << 32) && c_bytes < (1ull << 31);
+}
+
 int launch_conv_patch4(const GemmParams& p, int prec, hipStream_t s) {
-    if (!conv_patch3_eligible(p, prec)) return 1;
+    if (!conv_patch4_eligible(p, prec)) return 1;
     if (prec == DT_F16) return p.ups ? launch_w4<DT_F16, 1>(p, s) : launch_w4<DT_F16, 0>(p, s);
     return p.ups ? launch_w4<DT_BF16, 1>(p, s) : launch_w4<DT_BF16, 0>(p, s);
 }

@@ -690,7 +690,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     }
     // conv3x3 with enough 16x16 patches to fill the chip: LDS-patch kernel (conv_patch.hip)
     const int ptiles = opt_patch ? conv_patch_tiles(p, P) : 0;
-    bool use_patch = ptiles >= 192;
+    bool use_patch = ptiles >= ncu * 3 / 4;   // (192 of 256 CUs: a launch that fills three quarters of the chip takes the patch kernel unsplit)
     // 16x16-level convs: too few 16x16 patches for the chip, but the patch kernel still beats the generic gather when the
     // channel chunks are split across 2-4 slices (fp32 slabs + the same deterministic finalize pass as the GEMM's split-K)
     int patch_split = 1;
@@ -718,7 +718,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !fp8 && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
         const int kmin = fp8 ? 8 : 16, kper = fp8 ? 4 : 8;   // an e4m3 K step carries twice the K of a 2-byte one
         if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= kmin && m.N % 4 == 0) {
-            splitk = (512 + tiles - 1) / tiles;
+            splitk = (2 * ncu + tiles - 1) / tiles;   // about two blocks per CU
             if (splitk > ktiles / kper) splitk = ktiles / kper;
             if (splitk > opt_splitk_max) splitk = opt_splitk_max;
             if (splitk < 1) splitk = 1;
@@ -732,20 +732,20 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         // split-K conv3x3 with at least 1024 rows (the 8x8 level at batch 8): 256-row tiles halve the weight bytes each slice streams
         // (every M tile reads the whole [160 x K / splitk] weight panel) when 256-row tiles x slices still give every CU a block
         const bool sk256 = opt_splitk_big && splitk > 1 && !p.tile_cnt && m.taps == 9 && !f32 && p.M >= 1024 &&
-                           ((p.M + 255) / 256) * ((m.N + 159) / 160) * splitk >= 256;
+                           ((p.M + 255) / 256) * ((m.N + 159) / 160) * splitk >= ncu;
         // the consumer sums the slabs itself (SlabDefer): plain bias / time-embedding epilogue only
         if (defer && defer->allow && splitk > 1 && !p.tile_cnt && p.slab && plain && act == 0 && scale == 1.f && !R && !VT && !ln_in && !ln_out && !m.geglu) {
             p.defer_finalize = 1;
             defer->active = true;
         }
         // 256-row tiles when they still give every CU a block (1 block of 8 waves per CU)
-        p.big_tile = ((opt_bigtile && splitk == 1 && ((p.M + 255) / 256) * ((m.N + 159) / 160) >= 256) || sk256) ? 1 : 0;
+        p.big_tile = ((opt_bigtile && splitk == 1 && ((p.M + 255) / 256) * ((m.N + 159) / 160) >= ncu) || sk256) ? 1 : 0;
         if (dense8 && tiles < opt_splitk_tiles) p.big_tile = 2;
         // 256 x 320 tiles for linear layers that still give (almost) every CU a block
         {
             const int t3 = ((p.M + 255) / 256) * ((m.N + 319) / 320);
-            const int rounds = (t3 + 255) / 256;
-            if (opt_wide && splitk == 1 && m.taps == 1 && in.dt == T && t3 >= 256 && t3 * 100 >= rounds * 256 * 85) p.big_tile = 3;
+            const int rounds = (t3 + ncu - 1) / ncu;
+            if (opt_wide && splitk == 1 && m.taps == 1 && in.dt == T && t3 >= ncu && t3 * 100 >= rounds * ncu * 85) p.big_tile = 3;
         }
         // short-K linear layers are HBM-bound (K <= 1280: 1.5-2.5x their traffic floor): what they need is loads and
         // stores of one tile overlapping the MFMAs of others, i.e. many waves per CU rather than a big tile -- the
@@ -753,7 +753,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         if (opt_short_k > 0 && splitk == 1 && m.taps == 1 && in.dt == T && !m.geglu && ktiles <= opt_short_k) p.big_tile = 2;
         // widths that are multiples of 192 but not of 160 (MMDiT hidden size 1536 and its 3x / 4x): the 256 x 192 tile
         if (opt_tile192 && !f32 && P != PREC_F16X2 && splitk == 1 && m.taps == 1 && (in.dt == T || fp8) && !m.geglu && m.N % 192 == 0 && m.N % 160 != 0 &&
-            ((p.M + 255) / 256) * (m.N / 192) >= 192)
+            ((p.M + 255) / 256) * (m.N / 192) >= ncu * 3 / 4)
             p.big_tile = 4;
         if (P == PREC_F16X2 && m.geglu && p.big_tile == 3) p.big_tile = 1;   // the 256 x 320 GEGLU tile spills with the split-operand fragments
         if (!p.defer_finalize) arena.release(mk);  // stream-ordered: the slab is dead once this GEMM's finalize pass has run
@@ -761,13 +761,13 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         // (almost) every CU one
         if (opt_ring > 0 && splitk == 1 && !fp8 && ktiles <= opt_ring && (p.act != 2 || opt_ring_geglu) && ring_gemm_eligible(p, P)) {
             use_ring = true;
-            ring_tile = opt_ring_tile >= 0 ? opt_ring_tile : (((p.M + 255) / 256) * ((m.N + 159) / 160) >= 224 ? 1 : 0);
+            ring_tile = opt_ring_tile >= 0 ? opt_ring_tile : (((p.M + 255) / 256) * ((m.N + 159) / 160) >= ncu * 7 / 8 ? 1 : 0);
             // ping-pong form (two wave groups half a K step apart; bit-identical): -10..-14 % on long reductions and -3..-5 % on one
             // 256-row tile per CU; +6..+13 % where a block walks several short tiles (the groups' epilogues serialise) -- tools/micro/ring_pp.hip
             if (opt_ring_pp && ring_tile < 2 && p.act != 2) {
                 const int bm = ring_tile ? 256 : 128;
                 const int nblk = ((p.M + bm - 1) / bm) * ((m.N + 159) / 160);
-                if (ktiles >= 40 || (ring_tile == 1 && nblk <= 256)) ring_tile += 2;
+                if (ktiles >= 40 || (ring_tile == 1 && nblk <= ncu)) ring_tile += 2;
             }
             p.big_tile = 0;
         }
@@ -821,7 +821,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     const bool patch2 = use_patch && opt_patch2 && !f32 && !gn_coef && (patch_split > 1 || ptiles >= opt_patch2_tiles);
     // fourth generation (4 waves per block, one per SIMD, 32x32x16 MFMAs, LDS-DMA operands): every unsplit 2-byte launch (-4..-8 % at
     // batch 8, -17..-19 % at batch 1 against the faster of the first two; split-K launches tie and stay on the second)
-    const bool patch4 = use_patch && opt_patch4 && patch_split == 1 && p.act == 0 && conv_patch3_eligible(p, P);
+    const bool patch4 = use_patch && opt_patch4 && patch_split == 1 && conv_patch4_eligible(p, P);
     if (use_patch ? (patch4 ? launch_conv_patch4(p, P, stream) : patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream))
                   : use_ring ? launch_ring_gemm(p, prec, ring_tile, stream) : launch_gemm(p, prec, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -912,7 +912,7 @@ int pd_engine::conv_gn(const ConvW& c, const Act& x, Act& out, const float* g, c
     GemmParams q{};
     q.M = (int)out.rows(); q.N = c.m.N; q.K = c.m.K; q.taps = c.m.taps; q.Cin = c.m.cin_pad; q.stride = c.stride;
     q.Hin = x.H; q.Win = x.W; q.Hout = out.H; q.Wout = out.W; q.a_dt = x.dt; q.vt_begin = INT_MAX; q.splitk = 1;
-    const bool fuse = opt_gn_fuse && opt_patch && x.C == c.m.cin_pad && conv_patch_tiles(q, P) >= 192;
+    const bool fuse = opt_gn_fuse && opt_patch && x.C == c.m.cin_pad && conv_patch_tiles(q, P) >= ncu * 3 / 4;
     if (!fuse) {
         const size_t mk = arena.mark();
         Act a = new_act(x.B, x.H, x.W, x.C, T);

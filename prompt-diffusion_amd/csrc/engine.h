@@ -250,6 +250,7 @@ struct Session {
 struct pd_engine {
     pd_config cfg{};
     int device = 0;
+    int ncu = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount): the tile / split-K rules scale with it
     hipStream_t stream = nullptr;
     bool f32 = false;   // fp32 storage of activations and weights (PD_PREC_F32 and PD_PREC_F16X2)
     int P = DT_BF16;    // MFMA precision code handed to the contraction launchers: T, or PREC_F16X2
@@ -286,7 +287,7 @@ struct pd_engine {
     bool opt_splitk_fused = false; // split-K sums + epilogue run in the last-arriving slice instead of a finalize kernel
     int opt_splitk_max = 8;
     int opt_splitk_big = 0;       // split-K conv3x3 on 256 x 160 tiles where that still fills the chip (option "splitk_big")
-    int opt_splitk_tiles = 384;   // split K when the 128x160 tile grid has fewer blocks than this
+    int opt_splitk_tiles = 384;   // (x ncu / 256 at build)   // split K when the 128x160 tile grid has fewer blocks than this
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
     int opt_dense_tiles = 128;

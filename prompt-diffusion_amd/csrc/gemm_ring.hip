@@ -19,6 +19,7 @@
 // The MFMA / epilogue side is igemm_kernel's (16x16x32 "swapped" MFMAs, a lane owns 4 consecutive output channels).
 #include "pd_common.h"
 #include "pd_mma.h"
+#include "pd_stamp.h"
 
 namespace {
 
@@ -39,15 +40,8 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
 // Diagnostic build only (tools/micro/ring_stamp.hip compiles this file with -DPD_STAMP): cycles wave 0 of every block spends in
-// each part of its step loop.  No stamp executes in the product build.
-#ifdef PD_STAMP
-__device__ unsigned long long* g_ring_stamps = nullptr;
-#define RT_NOW() ([]() { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); return t_; }())
-#define RT_ADD(acc, a, b) acc += (b) - (a)
-#else
-#define RT_NOW() 0ull
-#define RT_ADD(acc, a, b) do { } while (0)
-#endif
+// each part of its step loop (pd_stamp.h; nothing of it exists in the product build).
+PD_T_ONLY(__device__ unsigned long long* g_ring_stamps = nullptr;)
 
 // GG: the GEGLU epilogue (act == 2; weights pre-interleaved so that virtual columns [0, 80) of each 160-column block are x and
 // [80, 160) the gate): WN = 1, a wave owns whole blocks and writes x * gelu(gate), 80 columns per block.
@@ -99,11 +93,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
     };
     int pj = 0, pkt = 0, pslot = 0;
     auto issue = [&]() __attribute__((always_inline)) {
-#ifdef PD_KO_DMA   // diagnostic build (tools/micro/ring_stamp.hip): no operand ever requested -- what do barrier + ds_read + MFMA take?
-        if (++pkt == KT) { pkt = 0; ++pj; }
-        pslot = pslot + 1 == NS ? 0 : pslot + 1;
-        return;
-#endif
         const char* As = reinterpret_cast<const char*>(p.A) + (size_t)pkt * BKB;
         const char* Ws = reinterpret_cast<const char*>(p.W) + (size_t)pkt * BKB;
         const unsigned dst = lds0 + (unsigned)pslot * STAGE + (unsigned)wave * 8 * BKB;
@@ -141,19 +130,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
             uint4 af[MT], wf[NT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-#ifdef PD_KO_DSREAD   // diagnostic build: MFMAs on whatever the registers hold
-                asm volatile("" : "=v"(af[m]));
-#else
                 af[m] = *reinterpret_cast<const uint4*>(sa + swz(wm * WTM + m * 16 + fr, ks * 4 + fq));
-#endif
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-#ifdef PD_KO_DSREAD
-                asm volatile("" : "=v"(wf[n]));
-#else
                 wf[n] = *reinterpret_cast<const uint4*>(sb + swz(wn * WTN + n * 16 + fr, ks * 4 + fq));
-#endif
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -192,7 +173,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
     // still has the current tile's epilogue ahead of it)
     float2* sLn = reinterpret_cast<float2*>(smem + NS * STAGE);
     [[maybe_unused]] unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_mma = 0, c_epi = 0;
-    [[maybe_unused]] const unsigned long long t_begin = RT_NOW();
+    [[maybe_unused]] const unsigned long long t_begin = PD_T_NOW();
     setup(0);
     int issued = 0;
     for (; issued < NS - 1 && issued < G; ++issued) issue();
@@ -257,11 +238,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
             }
         } else
         for (int kt = 0; kt < KT; ++kt) {
-            [[maybe_unused]] const unsigned long long t0 = RT_NOW();
+            [[maybe_unused]] const unsigned long long t0 = PD_T_NOW();
             wait_stage(issued - 1 - (i * KT + kt));
-            [[maybe_unused]] const unsigned long long t1 = RT_NOW();
+            [[maybe_unused]] const unsigned long long t1 = PD_T_NOW();
             asm volatile("s_barrier" ::: "memory");
-            [[maybe_unused]] const unsigned long long t2 = RT_NOW();
+            [[maybe_unused]] const unsigned long long t2 = PD_T_NOW();
             if (kt == 0 && p.ln_stats && tid < BM) {   // behind the barrier: every wave has left the previous tile's epilogue
                 const int gm = bm * BM + tid;
                 float mean = 0.f, rstd = 0.f;
@@ -282,16 +263,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
                     }
                 }
             }
-            [[maybe_unused]] const unsigned long long t3 = RT_NOW();
+            [[maybe_unused]] const unsigned long long t3 = PD_T_NOW();
             compute(cslot);
             cslot = cslot + 1 == NS ? 0 : cslot + 1;
-#ifdef PD_STAMP
-            asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[NT - 1][MT - 1]));   // the step's MFMAs are issued before the stamp
-#endif
-            [[maybe_unused]] const unsigned long long t4 = RT_NOW();
-            RT_ADD(c_wait, t0, t1); RT_ADD(c_bar, t1, t2); RT_ADD(c_issue, t2, t3); RT_ADD(c_mma, t3, t4);
+            PD_T_ONLY(asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[NT - 1][MT - 1]));)   // the step\'s MFMAs are issued before the stamp
+            [[maybe_unused]] const unsigned long long t4 = PD_T_NOW();
+            PD_T_ADD(c_wait, t0, t1); PD_T_ADD(c_bar, t1, t2); PD_T_ADD(c_issue, t2, t3); PD_T_ADD(c_mma, t3, t4);
         }
-        [[maybe_unused]] const unsigned long long t5 = RT_NOW();
+        [[maybe_unused]] const unsigned long long t5 = PD_T_NOW();
         if constexpr (GG) {
             // ---- GEGLU epilogue: out[:, 80 bn + j] = (x_j + b_j) * gelu(g_j + b_{80 + j}); the bias reads go first (see above)
 #pragma unroll
@@ -309,8 +288,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
                     if (gm < p.M && on < p.Nout) store4(p.C, (size_t)gm * p.ldc + on, p.c_dt, o);
                 }
             }
-            [[maybe_unused]] const unsigned long long t6g = RT_NOW();
-            RT_ADD(c_epi, t5, t6g);
+            [[maybe_unused]] const unsigned long long t6g = PD_T_NOW();
+            PD_T_ADD(c_epi, t5, t6g);
             continue;
         }
         // ---- epilogue (pd_mma.h epilogue4's arithmetic): a lane holds channels gn .. gn + 3 of row gm
@@ -369,11 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
                         for (int c = 0; c < 4; ++c) o[base + (size_t)c * p.vt_ld] = cvt16_rt(v[c], p.c_dt);
                     }
                 } else {
-#ifdef PD_KO_COALESCED   // diagnostic build: the same bytes, but every store instruction writes 512 contiguous bytes (wrong places)
-                    store4(p.C, min((size_t)(bm * ntiles + bn) * BM * BN + (size_t)((wave * MT + m) * NT + n) * 256, (size_t)p.M * p.N - 256) + lane * 4, p.c_dt, v);
-#else
                     store4(p.C, (size_t)gm * p.ldc + gn, p.c_dt, v);
-#endif
                 }
                 rs += (v[0] + v[1]) + (v[2] + v[3]);
                 rq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -388,15 +363,13 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void rgemm_kernel(GemmParams p) {
                 }
             }
         }
-        [[maybe_unused]] const unsigned long long t6 = RT_NOW();
-        RT_ADD(c_epi, t5, t6);
+        [[maybe_unused]] const unsigned long long t6 = PD_T_NOW();
+        PD_T_ADD(c_epi, t5, t6);
     }
-#ifdef PD_STAMP
-    if (threadIdx.x == 0 && g_ring_stamps) {
+    PD_T_ONLY(if (threadIdx.x == 0 && g_ring_stamps) {
         unsigned long long* o = g_ring_stamps + (size_t)blockIdx.x * 8;
-        o[0] = t_begin; o[1] = RT_NOW(); o[2] = c_wait; o[3] = c_bar; o[4] = c_issue; o[5] = c_mma; o[6] = c_epi; o[7] = (unsigned long long)nmy;
-    }
-#endif
+        o[0] = t_begin; o[1] = PD_T_NOW(); o[2] = c_wait; o[3] = c_bar; o[4] = c_issue; o[5] = c_mma; o[6] = c_epi; o[7] = (unsigned long long)nmy;
+    })
 }
 
 template <int P, int BM, int BN, int WM, int WN, int NS, bool GG = false, bool PP = false>
@@ -432,11 +405,13 @@ bool ring_gemm_eligible(const GemmParams& p, int prec) {
 // tile: 0 = 128 x 160 (4 stages), 1 = 256 x 160 (3 stages); both 4 x 2 waves.  GEGLU layers (act 2): 256 x 160 on 8 x 1 waves.
 int launch_ring_gemm(const GemmParams& p, int prec, int tile, hipStream_t s) {
     if (!ring_gemm_eligible(p, prec)) return 1;
-    static int ncu = 0;
+    static int ncu_of[64] = {};   // per device id (engines on different devices share the process)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    int& ncu = ncu_of[dev & 63];
     if (!ncu) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
         ncu = prop.multiProcessorCount;
         if (ncu < 8) return 1;
     }

@@ -233,9 +233,8 @@ int launch_splitk_finalize(const GemmParams& p, hipStream_t s);   // sums p.spli
 int conv_patch_tiles(const GemmParams& p, int prec);  // 0: shape not eligible for the LDS-patch conv kernel
 int launch_conv_patch(const GemmParams& p, int prec, hipStream_t s);
 int launch_conv_patch2(const GemmParams& p, int prec, hipStream_t s);   // conv_patch2.hip: compute / loader wave specialisation (2-byte types)
-bool conv_patch3_eligible(const GemmParams& p, int prec);              // conv_patch3.hip: LDS-DMA operands, two wave groups half a unit apart (2-byte types)
-int launch_conv_patch3(const GemmParams& p, int prec, hipStream_t s);
-int launch_conv_patch4(const GemmParams& p, int prec, hipStream_t s);   // conv_patch4.hip: 4 waves per block, one per SIMD, 32x32x16 MFMAs (same eligibility)
+bool conv_patch4_eligible(const GemmParams& p, int prec);              // conv_patch4.hip: 4 waves per block, one per SIMD, 32x32x16 MFMAs, LDS-DMA operands (2-byte types)
+int launch_conv_patch4(const GemmParams& p, int prec, hipStream_t s);
 int launch_attention(const AttnParams& p, int prec, hipStream_t s);
 // st_tail.hip: everything after the self-attention product of a 320-channel SpatialTransformer block in one kernel (attn1.to_out +
 // residual, norm2, attn2 against the hoisted context K / V, norm3, GEGLU feed-forward, proj_out + the block residual)

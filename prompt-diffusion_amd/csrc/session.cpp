@@ -460,6 +460,13 @@ int pd_engine_create(const pd_config* cfg, int device_id, pd_engine** out) {
     pd_engine* e = new pd_engine();
     e->cfg = *cfg;
     e->device = device_id;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount >= 8) {
+            e->ncu = prop.multiProcessorCount;
+            e->opt_splitk_tiles = e->opt_splitk_tiles * e->ncu / 256;   // the defaults are written for 256 CUs
+        }
+    }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
         pd_set_error("hipStreamCreate failed");
         delete e;

@@ -1,3 +1,6 @@
+// Launch timing of conv_patch.hip (first-generation patch conv) on random / constant, warm / cold operands.  Its s_memtime stamps were
+// retired in round 4 (the stamped numbers are kept in profiles/r03_conv_stamp.txt; git history has the stamped kernel); -DPD_STAMP no longer
+// has an effect here.  The stamped generation is conv_patch4.hip: tools/micro/conv_w4_stamp.hip.  Original header:
 // Diagnostic build of conv_patch.hip with s_memtime accumulators (wave 0 of every block): where do a block's cycles go?
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPD_STAMP -w -Iprompt-diffusion_amd/csrc tools/micro/conv_stamp.hip -o /tmp/conv_stamp && /tmp/conv_stamp
 // Read the SHARES, not the lengths: the stamps' fences forbid overlaps the product build has.
@@ -30,9 +33,6 @@ int main() {
     const Shape shapes[] = {{16, 64, 320, 320, 1}, {16, 64, 320, 320, 0}, {16, 32, 640, 640, 1}, {16, 64, 640, 320, 1}, {16, 16, 1280, 1280, 1}};
     unsigned long long* stamps;
     hipMalloc(&stamps, 4096 * 18 * 8);
-#ifdef PD_STAMP
-    hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &stamps, sizeof(stamps));
-#endif
     for (const Shape& sh : shapes) {
         const long long M = (long long)sh.B * sh.H * sh.H;
         const int K = 9 * sh.Cin;
@@ -82,7 +82,7 @@ int main() {
             std::sort(d.begin(), d.end());
             return d[d.size() / 2];
         };
-#ifndef PD_STAMP
+#if 1
         printf("conv3x3 B=%d %dx%d Cin=%d Cout=%d res=%d: %.1f us per launch (%.0f TF/s)\n", sh.B, sh.H, sh.H, sh.Cin, sh.Cout, sh.res, ms * 100.0, 2.0 * M * sh.Cout * K / (ms * 1e-4) / 1e12);
         continue;
 #endif

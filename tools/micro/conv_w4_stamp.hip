@@ -7,7 +7,6 @@
 #include <vector>
 
 int launch_splitk_finalize(const GemmParams&, hipStream_t) { return 0; }   // (gemm.hip's; never reached: no split-K below)
-bool conv_patch3_eligible(const GemmParams&, int) { return true; }
 
 static void fill_random(void* p, size_t bytes, unsigned seed) {
     std::vector<uint16_t> h(bytes / 2);
