@@ -192,7 +192,9 @@ int pd_wait_stream(pd_engine* e, void* producer);
  *   "verbose", "profile" (HIP events around every contraction launch, see pd_profile_read),
  *   "two_streams" (ControlNet on a second stream beside the UNet encoder, default 1),
  *   "graph" (pd_ddim_sample captures its step loop in a hipGraph and replays it on later calls with equal arguments, 0),
- *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "conv_patch2" (its wave-specialised second generation in the 2-byte modes, 1), "patch_split" / "patch_split_tiles" (that kernel with the channel chunks
+ *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "conv_patch2" (its wave-specialised second generation in the 2-byte modes, 1), "patch4" (the
+ *   fourth generation -- 4 waves per block, one per SIMD, 32x32x16 MFMAs, LDS-DMA operands -- for every unsplit 2-byte patch conv, 1;
+ *   bit-identical to the others), "patch_split" / "patch_split_tiles" (that kernel with the channel chunks
  *   split over 2-4 slices when it has fewer tiles than CUs but at least this many, 1 / 64), "gn_fuse" (GroupNorm applied while the patch is staged, 0),
  *   "ln_fuse" (norm1 / norm2 of a transformer block folded into the to_q/k/v and attn2.to_q GEMMs, row statistics carried
  *   from the producing GEMM's epilogue: -1 = on in the 2-byte modes and off in the fp32-storage modes, 0 / 1 forced),
@@ -210,7 +212,8 @@ int pd_wait_stream(pd_engine* e, void* producer);
  *   "st_fuse" (320-channel SpatialTransformer blocks: st_front / st_tail fused kernels in the 2-byte modes, 1),
  *   "ring" / "ring_tile" / "ring_geglu" (gemm_ring.hip: linear layers over 2-byte operands with at most that many 64-element K steps
  *   take the persistent LDS-DMA ring GEMM, 80 / its tile -1 auto, 0 = 128x160, 1 = 256x160 / GEGLU projections too, 1; results are
- *   bit-identical to the igemm tiles'), "slab_gn" (a ResBlock conv1 that runs split-K hands its fp32 slabs to the single-kernel
+ *   bit-identical to the igemm tiles'), "ring_pp" (its ping-pong form -- two wave groups half a K step apart -- for K >= 2560 and for one
+ *   256-row tile per CU, 1; bit-identical), "slab_gn" (a ResBlock conv1 that runs split-K hands its fp32 slabs to the single-kernel
  *   GroupNorm that reads them instead of running a finalize pass, 1; bit-identical), "patch_split_min" (patch-conv split-K: at
  *   least this many 128-byte channel chunks per slice, 4). */
 int pd_set_option(pd_engine* e, const char* key, int64_t value);
@@ -219,7 +222,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value);
 int64_t pd_get_stat(pd_engine* e, const char* key);
 /* Per-launch timing: while option "profile" is 1 the engine brackets every contraction launch with HIP
  * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel / rgemm_kernel on a conv1x1/linear,
- * 2 = attention, 3 = conv3x3_patch_kernel, 4 = st_front / st_tail, -1 = all.  One bracket = one launch (split-K finalize excluded).
+ * 2 = attention, 3 = the conv3x3 patch kernels (all generations), 4 = st_front / st_tail, -1 = all.  One bracket = one launch (split-K finalize excluded).
  * Returns summed device time, launch count and algorithmic FLOPs (2*M*N*K, logical channel counts).  The elapsed time of
  * a bracket around an empty one-block kernel, calibrated when "profile" is switched on (stat "event_overhead_ns"), is
  * taken off every bracket. */

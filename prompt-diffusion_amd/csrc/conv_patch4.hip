@@ -314,14 +314,25 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
         const __amdgpu_buffer_rsrc_t rc_ = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((size_t)p.M * p.ldc * 2), 0x00020000);
         const int ldr = hr ? p.ldr : 0;
         const int gn0 = bn * BN + lh * 4;   // + 32 n + 8 g
+        // wide = 16-byte accesses: the two lane halves of a pixel exchange the halves of two neighbouring channel groups (v_permlane32_swap),
+        // after which a lane owns 8 consecutive channels -- one store instruction then writes 32 contiguous bytes per pixel (as the 16x16
+        // kernels do; the 8-byte form measured 2.6x the output bytes at the memory side) in half as many instructions, and the residual
+        // comes in the same way.  Needs whole 16-byte pieces: N, ldc, ldr multiples of 8.
+        const bool wide = p.N % 8 == 0 && p.ldc % 8 == 0 && (!hr || p.ldr % 8 == 0);
+        const int gn1 = bn * BN + lh * 8;   // wide: + 32 n + 8 g (g even)
         unsigned ro[2], co[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int tok = (y0 + 4 * wave + 2 * m + (l31 >> 4)) * p.Wout + x0 + (l31 & 15);
             const unsigned gm = (unsigned)(sample * p.rows_per_sample + tok);
-            ro[m] = (gm * (unsigned)ldr + (unsigned)gn0) * 2u;
-            co[m] = (gm * (unsigned)p.ldc + (unsigned)gn0) * 2u;
+            ro[m] = (gm * (unsigned)ldr + (unsigned)(wide ? gn1 : gn0)) * 2u;
+            co[m] = (gm * (unsigned)p.ldc + (unsigned)(wide ? gn1 : gn0)) * 2u;
         }
+        auto swap2 = [](uint2& a, uint2& b) __attribute__((always_inline)) {   // lanes 32-63 of a <-> lanes 0-31 of b, both dwords
+            auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+            auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+            a.x = rx[0]; b.x = rx[1]; a.y = ry[0]; b.y = ry[1];
+        };
         // two halves of 10 channel groups (both pixels): the second half's bias / time-embedding rows are requested once the first half's
         // results are packed, still in front of the first store -- 120 + 40 instead of 240 operand registers
         f32x4 eb[10], ev[10];
@@ -358,7 +369,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
                 static_for<10>([&](auto Q) {
                     constexpr int qq = 10 * h + decltype(Q)::value, q = decltype(Q)::value;
                     constexpr int coff = (qq >> 2) * 32 + (qq & 3) * 8;
-                    if (gn0 + coff < p.N) { typedef unsigned int u32x2_t __attribute__((__vector_size__(8))); __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, out[m][q]), rc_, co[m], coff * 2, 0); }
+                    if (!wide) {
+                        if (gn0 + coff < p.N) { typedef unsigned int u32x2_t __attribute__((__vector_size__(8))); __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, out[m][q]), rc_, co[m], coff * 2, 0); }
+                    } else if constexpr ((qq & 1) == 0) {
+                        // groups g (even) and g + 1: lower lanes end with [own g | upper's g] = channels 8 g .. 8 g + 7, upper lanes with
+                        // [lower's g + 1 | own g + 1] = the next 8
+                        uint2 a = out[m][q], b = out[m][q + 1];
+                        swap2(a, b);
+                        if (gn1 + coff < p.N) __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, b.x, b.y}, rc_, co[m], coff * 2, 0);
+                    }
                 });
             });
         };
@@ -367,9 +386,21 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
             constexpr int m = decltype(MC)::value;
             static_for<20>([&](auto Q) {
                 constexpr int qq = decltype(Q)::value;
-                er[m][qq] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rr, ro[m], ((qq >> 2) * 32 + (qq & 3) * 8) * 2, 0));
+                constexpr int coff = (qq >> 2) * 32 + (qq & 3) * 8;
+                if (!wide) {
+                    er[m][qq] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rr, ro[m], coff * 2, 0));
+                } else if constexpr ((qq & 1) == 0) {   // 16 bytes = this lane's 8 channels of the pair (g, g + 1); un-swapped below
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr, ro[m], coff * 2, 0);
+                    er[m][qq] = make_uint2(t[0], t[1]);
+                    er[m][qq + 1] = make_uint2(t[2], t[3]);
+                }
             });
         });
+        if (wide) {   // X = first halves, Y = second halves: after the swap X is group g for both lane halves, Y group g + 1
+            static_for<2>([&](auto MC) {
+                static_for<10>([&](auto Q) { swap2(er[decltype(MC)::value][2 * decltype(Q)::value], er[decltype(MC)::value][2 * decltype(Q)::value + 1]); });
+            });
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll

@@ -44,9 +44,22 @@ int main() {
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         float t[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+#ifdef COLD   // every launch reads operands that left the caches long ago: NB copies of input, weights and residual in turn (> 256 MB together)
+        constexpr int NB = 12;
+        static void *as[NB], *ws[NB], *rs[NB];
+        for (int i = 0; i < NB; ++i) {
+            (void)hipMalloc(&as[i], ab); (void)hipMalloc(&ws[i], wb); (void)hipMalloc(&rs[i], cb);
+            (void)hipMemcpy(as[i], a, ab, hipMemcpyDeviceToDevice); (void)hipMemcpy(ws[i], w, wb, hipMemcpyDeviceToDevice); (void)hipMemcpy(rs[i], r, cb, hipMemcpyDeviceToDevice);
+        }
+        int turn = 0;
+#endif
         auto run = [&](int v) {
             GemmParams q = p;
             q.C = c[v]; q.slab = slab[v];
+#ifdef COLD
+            q.A = as[turn % NB]; q.W = ws[turn % NB]; if (sh.res) q.R = rs[turn % NB];
+            ++turn;
+#endif
             return v == 0 ? launch_conv_patch(q, DT_F16, 0) : v == 1 ? launch_conv_patch2(q, DT_F16, 0) : v == 2 ? 0 : launch_conv_patch4(q, DT_F16, 0);
         };
         int fail = 0;
@@ -70,7 +83,7 @@ int main() {
             (void)hipMemcpy(h1.data(), c[v], cb, hipMemcpyDeviceToHost);
             for (size_t i = 0; i < h0.size(); ++i) {
                 diff[v] += h0[i] != h1[i];
-                if (v >= 2) { const double a = h2f(h0[i]), b = h2f(h1[i]); maxd = std::max(maxd, b != b ? 1e30 : std::abs(a - b)); maxv = std::max(maxv, std::abs(a)); }
+                if (v == 3) { const double a = h2f(h0[i]), b = h2f(h1[i]); maxd = std::max(maxd, b != b ? 1e30 : std::abs(a - b)); maxv = std::max(maxv, std::abs(a)); }
             }
         }
         const double fl = 2.0 * M * sh.Cout * K;
@@ -78,7 +91,10 @@ int main() {
                sh.B, sh.H, sh.H, sh.Cin, sh.Cout, sh.res, sh.ups, sh.splitk, tiles, fail, t[0], fl / t[0] / 1e6, t[1], fl / t[1] / 1e6, t[2], fl / t[2] / 1e6, t[3], fl / t[3] / 1e6,
                100.0 * (t[3] / std::min(t[0], t[1]) - 1.0), diff[1], diff[2], diff[3], maxd, maxv);
         fflush(stdout);
-        bad += maxd > 4e-3 * maxv || fail;
+        bad += diff[3] != 0 || fail;   // (column 2, the retired ping-pong generation, is not run)
+#ifdef COLD
+        for (int i = 0; i < NB; ++i) { (void)hipFree(as[i]); (void)hipFree(ws[i]); (void)hipFree(rs[i]); }
+#endif
         (void)hipFree(a); (void)hipFree(w); (void)hipFree(r); (void)hipFree(bias);
         for (int v = 0; v < 4; ++v) { (void)hipFree(c[v]); if (slab[v]) (void)hipFree(slab[v]); }
     }
