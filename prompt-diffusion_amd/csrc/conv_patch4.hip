@@ -353,11 +353,17 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_w4_kernel(GemmParams p) {
             v = hb ? vb : v;
             const f32x4 vv = v + ev[q];
             v = hv ? vv : v;
-            v *= p.out_scale;
             float r0, r1, r2, r3;
             unpack2<P>(er[m][qq].x, r0, r1); unpack2<P>(er[m][qq].y, r2, r3);
-            const f32x4 vr = v + f32x4{r0, r1, r2, r3};
-            v = hr ? vr : v;
+            // scale, THEN the residual: two roundings, as the reference does it (cldm.py:379 multiplies the control tensor, :41 adds it) and as
+            // epilogue4_value ends up in the other generations.  Left to itself hipcc contracts the two statements into one fused
+            // multiply-add here (0.015 % of the outputs of a scaled launch then differ by one ulp of the storage type): the empty asm
+            // keeps the product a value of its own
+            const f32x4 sc = f32x4{p.out_scale, p.out_scale, p.out_scale, p.out_scale};
+            f32x4 vs = v * sc;
+            asm volatile("" : "+v"(vs));
+            const f32x4 vr = vs + f32x4{r0, r1, r2, r3};
+            v = hr ? vr : vs;
             uint2 o;
             o.x = pack2<P>(v[0], v[1]); o.y = pack2<P>(v[2], v[3]);
             return o;

@@ -95,6 +95,37 @@ def test_conv2d_patch_kernel_split_k(eng):
     assert relerr(base, ref) < TOL[eng.prec] and not np.array_equal(base, got)   # really a different kernel path
 
 
+@pytest.mark.parametrize("B,Cin,H,Cout,ups", [
+    (48, 64, 32, 168, False),    # 192 patches x 2 channel tiles (the second one ragged: 8 of 160), 16-byte epilogue accesses (N % 8 == 0)
+    (48, 128, 32, 164, False),   # N % 8 != 0: the 8-byte epilogue form; two channel chunks (the patch double buffer and the ring wrap)
+    (50, 64, 16, 96, True),      # fused nearest-x2 upsample: 200 patches, source patch 10 x 10
+])
+def test_conv2d_patch4_matches_first_generation(eng, B, Cin, H, Cout, ups):
+    """The 4-wave patch conv (conv_patch4.hip: one wave per SIMD, 32x32x16 MFMAs, LDS-DMA operands, zero padding by out-of-range
+    buffer loads) against the first generation (option patch4 = 0) on launches of >= 192 blocks: image borders in every block row /
+    column, ragged channel tile, bias / scale / residual epilogue.  The two MFMA shapes sum the same products in the same order:
+    bit-identical in the 2-byte modes (the fp32-storage modes never take the new kernel).  Both against the oracle."""
+    g = rng(21)
+    x = g.standard_normal((B, Cin, H, H), dtype=np.float32)
+    w = (g.standard_normal((Cout, Cin, 3, 3), dtype=np.float32) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = g.standard_normal(Cout, dtype=np.float32) * 0.1
+    Ho = 2 * H if ups else H
+    r = g.standard_normal((B, Cout, Ho, Ho), dtype=np.float32)
+    xin = np.repeat(np.repeat(x, 2, axis=2), 2, axis=3) if ups else x
+    ref = O.conv2d(xin, w, b)
+    try:
+        eng.set_option("patch4", 1)
+        y1 = eng.op_conv2d(x, w, b, upsample=ups)
+        y1r = eng.op_conv2d(x, w, b, upsample=ups, scale=0.75, residual=r, stream_out=True)
+        eng.set_option("patch4", 0)
+        y0 = eng.op_conv2d(x, w, b, upsample=ups)
+        y0r = eng.op_conv2d(x, w, b, upsample=ups, scale=0.75, residual=r, stream_out=True)
+    finally:
+        eng.set_option("patch4", 1)
+    assert relerr(y1, ref) < TOL[eng.prec] and relerr(y1r, ref * 0.75 + r) < TOL[eng.prec]
+    assert np.array_equal(y1, y0) and np.array_equal(y1r, y0r)
+
+
 def test_conv2d_epilogues(eng):
     g = rng(2)
     x = g.standard_normal((2, 64, 8, 8), dtype=np.float32)
@@ -160,6 +191,12 @@ def test_linear_ring_kernel(eng, tile):
             n0 = eng.stat("ring_launches")
             y = eng.op_linear(x, w, b)
             assert eng.stat("ring_launches") == n0 + 1, ("the ring kernel did not take this layer", M, K, N)
+            # its ping-pong form (two wave groups half a K step apart; default where it measures faster: K >= 2560, or one 256-row
+            # tile per CU) and its lockstep form are the same arithmetic in the same order
+            eng.set_option("ring_pp", 0)
+            assert np.array_equal(eng.op_linear(x, w, b), y), ("ping-pong vs lockstep", M, K, N)
+            eng.set_option("ring_pp", 1)
+            n0 += 1
             eng.set_option("ring", 0)
             y0 = eng.op_linear(x, w, b)
             assert eng.stat("ring_launches") == n0 + 1
@@ -186,7 +223,7 @@ def test_linear_ring_kernel(eng, tile):
             a_, gate = np.split(O.linear(x, w, b), 2, axis=-1)
             assert relerr(y, a_ * O.gelu(gate)) < TOL[eng.prec] and np.array_equal(y, y0), (M, Cc)
     finally:
-        eng.set_option("ring", 80); eng.set_option("ring_tile", -1); eng.set_option("ring_geglu", 1)
+        eng.set_option("ring", 80); eng.set_option("ring_tile", -1); eng.set_option("ring_geglu", 1); eng.set_option("ring_pp", 1)
 
 
 @pytest.mark.parametrize("M,C", [(200, 64), (64, 320), (33, 40)])
