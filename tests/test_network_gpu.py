@@ -369,6 +369,40 @@ def test_sd15_headline_schedule_per_step(golden_dir, tag, prec):
     e.close()
 
 
+def test_sd15_headline_schedule_f16_margin_under_another_summation_order(golden_dir):
+    """How thin the fp16 mode's margin on the metric's schedule is: letting the patch conv split K on more shapes
+    (patch_split_min = 1, patch_split_tiles = 32) changes nothing but the order of fp32 partial sums -- 1e-6 in the fp32 mode -- yet moves
+    single outputs by one fp16 ulp, and the first step's error against the reference's latent from 7.4e-4 to 1.02e-3.  The shipped order is
+    inside the north star's 1e-3 on every step (test_sd15_headline_schedule_per_step); this order is held to 1.1e-3 at the first step
+    and to 1e-3 from the second on -- the honest reading of the fp16 mode is 0.7-1.0e-3 at step 0 and <= 7.5e-4 afterwards, f16x2 (5e-6)
+    being the conforming mode."""
+    path = os.path.join(golden_dir, "net_sd15_b1_32x32_s50.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g = np.load(path)
+    cfg = W.SD15
+    keep = [int(k) for k in g["keep"]]
+    ref = {k: g["x_inter"][j] for j, k in enumerate(keep)}
+    inp = W.synth_inputs(cfg, int(g["B"]), int(g["h"]), int(g["w"]))
+    kw = dict(x_T=inp["x_T"], ctx_cond=inp["ctx_cond"], ctx_uncond=inp["ctx_uncond"], pair=inp["pair"], query=inp["query"],
+              steps=int(g["S"]), cfg_scale=float(g["cfg_scale"]))
+    e = _engine(cfg, "f16")
+    try:
+        e.set_option("patch_split_min", 1)
+        e.set_option("patch_split_tiles", 32)
+        e.sample_begin(**kw)
+        errs = []
+        for i in range(6):
+            e.sample_set_latents(ref[i])
+            e.sample_step(i)
+            errs.append(relerr(e.sample_get(), ref[i + 1]))
+        e.sample_end()
+    finally:
+        e.close()
+    print("f16, other split order: one-step relerr of steps 0-5", ["%.2e" % v for v in errs])
+    assert errs[0] < 1.1e-3 and max(errs[1:]) < NORTH_STAR
+
+
 @pytest.mark.parametrize("prec", ["f16", "f32"])
 def test_split_k_slabs_into_groupnorm_is_bit_identical(prec):
     """Option 'slab_gn' (default on): where a ResBlock's conv1 runs split-K and norm2 is the single-kernel GroupNorm (the
