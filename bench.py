@@ -169,6 +169,7 @@ def main():
                     help="skip the extra measurement of the f16x2 mode (fp32-class results) on the same workload")
     ap.add_argument("--no-parity", action="store_true", help="skip the per-step latent error leg")
     ap.add_argument("--no-sd3", action="store_true", help="skip the SD3 / MMDiT leg (SURVEY N4 / BASELINE config #5, context only)")
+    ap.add_argument("--engine-comm", action="store_true", help="N > 1: gather the final latents over the RCCL communicator the engine owns (pd_comm_*) instead of torch.distributed")
     ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=int (experiments)")
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise ControlNet and UNet on one stream in every pass (used for the committed rocprof summary, so\n"
@@ -225,9 +226,19 @@ def main():
     query = torch.rand((B, 3, 8 * h, 8 * w), generator=gen, device=dev) * 2 - 1
     kw = dict(x_T=x_T, ctx_cond=ctx_c, ctx_uncond=ctx_u, pair=pair, query=query, steps=S, cfg_scale=7.5, eta=0.0)
 
+    engine_comm = world > 1 and args.engine_comm and not rehearse
+    if engine_comm:
+        # the gather over the communicator the ENGINE owns (pd_comm_*: what a host without torch would use); the 128-byte id
+        # travels over the process group that the barrier and the timing exchange use anyway
+        box = [eng.comm_new_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.comm_init(box[0], world, rank)
+
     def one_pass():
         lat = eng.ddim_sample(**kw)          # blocking: stream-synchronised on return
-        if world > 1:
+        if engine_comm:
+            lat = eng.comm_all_gather(lat)
+        elif world > 1:
             lat = all_gather_latents(lat, sizes=[B] * world)    # the path's only exchange: ONE all-gather of the final latents over RCCL/xGMI
         return lat
 
@@ -259,7 +270,7 @@ def main():
         "metric": "images/sec @ 512x512, 50-step DDIM, bs=8", "value": value, "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic", "rccl_ranks": world,
+        "dtype": args.precision, "data": "synthetic", "rccl_ranks": world, "gather": "engine_rccl" if engine_comm else ("torch.distributed" if world > 1 else None),
         "backend": ("gloo (PD_BENCH_REHEARSE: every rank on device 0)" if rehearse else "nccl (RCCL)") if world > 1 else "none (single process)",
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "config": {"workload": f"SD1.5 UNet + Prompt-Diffusion ControlNet, {args.size}x{args.size}, {S}-step DDIM (eta 0), "

@@ -188,6 +188,20 @@ void* pd_stream(pd_engine* e);              /* hipStream_t the engine launches o
  * gives the reference (everything on torch's current stream).  Call before handing device buffers over; outputs need no
  * counterpart because every call that fills a caller buffer synchronises the engine stream before it returns. */
 int pd_wait_stream(pd_engine* e, void* producer);
+/* Multi-GPU: images are independent through every denoising step, so a batch shards over the GPUs of a node with
+ * no per-step exchange -- one process and one engine per GPU, exactly how the reference shards its evaluation set
+ * (eval/distributed.py:25-27 init_process_group, eval/evaluate_gen.py:55-57 batch_ids[rank::world_size]).  The one collective
+ * is an all-gather of the final latents over an RCCL communicator the engine owns (librccl is opened on first use):
+ *   rank 0: pd_comm_new_id(id) and hands the 128 bytes to every rank by any host channel (file, pipe, MPI, torch.distributed);
+ *   every rank: pd_comm_init(e, id, world, rank) (collective: returns once all ranks have joined), sample its shard, then
+ *   pd_comm_all_gather(e, my_latents, all_latents, count, mem): all_latents[world][count] in rank order, equal `count` on
+ *   every rank (pad ragged shards).  Without a communicator the gather is a copy (world 1). */
+#define PD_COMM_ID_BYTES 128
+int pd_comm_new_id(uint8_t id[PD_COMM_ID_BYTES]);
+int pd_comm_init(pd_engine* e, const uint8_t id[PD_COMM_ID_BYTES], int32_t world, int32_t rank);
+int pd_comm_world(pd_engine* e, int32_t* world, int32_t* rank);
+int pd_comm_all_gather(pd_engine* e, const float* send, float* recv, int64_t count, int32_t mem);
+int pd_comm_destroy(pd_engine* e); /* also done by pd_engine_destroy */
 /* Tuning / instrumentation knobs (defaults are the measured best; tests and tools/ flip them for A/B runs):
  *   "verbose", "profile" (HIP events around every contraction launch, see pd_profile_read),
  *   "two_streams" (ControlNet on a second stream beside the UNet encoder, default 1),

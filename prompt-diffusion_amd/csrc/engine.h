@@ -252,6 +252,8 @@ struct pd_engine {
     int device = 0;
     int ncu = 256;      // compute units of the device (hipDeviceProp_t::multiProcessorCount): the tile / split-K rules scale with it
     hipStream_t stream = nullptr;
+    void* comm = nullptr;   // ncclComm_t of pd_comm_init (comm.cpp); the final all-gather of a sharded batch
+    int comm_world = 1, comm_rank = 0;
     bool f32 = false;   // fp32 storage of activations and weights (PD_PREC_F32 and PD_PREC_F16X2)
     int P = DT_BF16;    // MFMA precision code handed to the contraction launchers: T, or PREC_F16X2
     int T = DT_BF16;  // compute (MFMA operand) type: DT_BF16, DT_F16 or DT_F32

@@ -481,6 +481,7 @@ void pd_engine_destroy(pd_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    (void)pd_comm_destroy(e);
     e->clear_graphs();
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
     for (hipEvent_t ev : e->sd3_ev) hipEventDestroy(ev);

@@ -5,6 +5,9 @@ stays on one GPU), so the path shards with NO per-step exchange -- exactly how t
 sampling (``batch_ids = np.arange(100)[rank::world_size]``, eval/evaluate_gen.py:55-57).  The only
 collective is one all-gather of the final latents (RCCL over xGMI: backend "nccl" on ROCm; "gloo" in the
 CPU tests).  One process per GPU.
+
+Two ways to run that gather: `all_gather_latents` over a torch.distributed group, or -- for a host without torch --
+`engine_comm_init` + `engine_all_gather_latents` over the RCCL communicator the engine owns (include/pdengine.h pd_comm_*).
 """
 from __future__ import annotations
 
@@ -63,3 +66,56 @@ def all_gather_latents(latents, group=None, sizes=None):
     if all(s == mx for s in sizes):
         return out
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)])
+
+
+def engine_comm_init(engine, rank: int, world: int, id_path: str, timeout_s: float = 120.0) -> None:
+    """Torch-free rendezvous for the engine-owned RCCL communicator: rank 0 writes the 128-byte id to `id_path` (a file every
+    rank of the node can read; written under a temporary name and renamed, so a reader never sees half of it), the others
+    wait for it, and every rank joins (`Engine.comm_init` is collective).  world == 1 needs no file."""
+    import os
+    import time
+    if world == 1:
+        engine.comm_init(engine.comm_new_id(), 1, 0)
+        return
+    if rank == 0:
+        tmp = "%s.%d.tmp" % (id_path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(engine.comm_new_id())
+        os.replace(tmp, id_path)
+    else:
+        t0 = time.monotonic()
+        while not os.path.exists(id_path):
+            if time.monotonic() - t0 > timeout_s:
+                raise TimeoutError("no communicator id at %s after %.0f s" % (id_path, timeout_s))
+            time.sleep(0.01)
+    with open(id_path, "rb") as f:
+        comm_id = f.read()
+    engine.comm_init(comm_id, world, rank)
+
+
+def engine_all_gather_latents(engine, latents, sizes=None):
+    """`all_gather_latents` over the engine's communicator: ONE ncclAllGather on the engine's stream.  `sizes` = the per-rank
+    shard sizes (shard_range is deterministic, so every rank can compute them); ragged shards are padded to the largest
+    and trimmed."""
+    world, rank = engine.comm_world()
+    n = latents.shape[0]
+    if sizes is None:
+        sizes = [n] * world
+    if len(sizes) != world or sizes[rank] != n:
+        raise ValueError("sizes must list every rank's shard size")
+    mx = max(sizes)
+    is_np = isinstance(latents, np.ndarray)
+    if n < mx:
+        if is_np:
+            latents = np.concatenate([latents, np.zeros((mx - n,) + latents.shape[1:], latents.dtype)])
+        else:
+            import torch
+            latents = torch.cat([latents, torch.zeros((mx - n,) + tuple(latents.shape[1:]), dtype=latents.dtype, device=latents.device)])
+    out = engine.comm_all_gather(latents)
+    if all(s == mx for s in sizes):
+        return out
+    parts = [out[r * mx:r * mx + sizes[r]] for r in range(world)]
+    if is_np:
+        return np.concatenate(parts)
+    import torch
+    return torch.cat(parts)

@@ -23,6 +23,7 @@ PD_DT_F32, PD_DT_F16, PD_DT_BF16 = 0, 1, 2
 PD_GET_LATENTS, PD_GET_PRED_X0, PD_GET_EPS = 0, 1, 2
 PD_MAX_LEVELS = 8
 PD_NUM_CONTROL = 13
+PD_COMM_ID_BYTES = 128
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libpdengine.so")
@@ -122,6 +123,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.pd_stream.restype = C.c_void_p
     lib.pd_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.pd_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.pd_comm_new_id.argtypes = [C.c_void_p]
+    lib.pd_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.pd_comm_world.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.pd_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    lib.pd_comm_destroy.argtypes = [C.c_void_p]
     lib.pd_get_stat.argtypes = [C.c_void_p, C.c_char_p]
     lib.pd_get_stat.restype = C.c_int64
     lib.pd_bench_conv3x3.argtypes = [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float)]
@@ -148,7 +154,7 @@ EXPORTS = [
     "pd_load_weights", "pd_init_random_weights", "pd_weights_missing", "pd_vae_weights_missing", "pd_vae_decode", "pd_eps", "pd_control_shape", "pd_ddim_sample",
     "pd_sample_begin", "pd_sample_step", "pd_sample_get", "pd_sample_set_latents", "pd_sample_set_guidance", "pd_sample_eps_at", "pd_sample_end",
     "pd_make_schedule", "pd_synchronize", "pd_stream", "pd_wait_stream", "pd_set_option", "pd_get_stat", "pd_bench_conv3x3", "pd_bench_linear", "pd_text_encode", "pd_text_encode_ex", "pd_text_weights_missing",
-    "pd_profile_read", "pd_profile_dump",
+    "pd_profile_read", "pd_profile_dump", "pd_comm_new_id", "pd_comm_init", "pd_comm_world", "pd_comm_all_gather", "pd_comm_destroy",
     "pd_sd3_configure", "pd_sd3_weights_missing", "pd_sd3_forward", "pd_sd3_control", "pd_sd3_sample", "pd_sd3_down_proj",
     "pd_op_conv2d", "pd_op_linear", "pd_op_linear_fp8", "pd_op_groupnorm", "pd_op_layernorm", "pd_op_attention", "pd_op_spatial_transformer", "pd_op_time_embed",
 ]
@@ -489,6 +495,44 @@ class Engine:
     def sample_end(self) -> None:
         self._check(self.lib.pd_sample_end(self._h))
         self._keep = []
+
+    # ------------------------------------------------------------------ multi-GPU
+    def comm_new_id(self) -> bytes:
+        """The 128-byte rendezvous token rank 0 creates and hands to every rank (any host channel)."""
+        buf = (C.c_uint8 * PD_COMM_ID_BYTES)()
+        self._check(self.lib.pd_comm_new_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, comm_id: bytes, world: int, rank: int) -> None:
+        """Join the engine-owned RCCL communicator (collective over all `world` ranks; one process and one engine per GPU)."""
+        if len(comm_id) != PD_COMM_ID_BYTES:
+            raise ValueError("comm_id must be the %d bytes of comm_new_id()" % PD_COMM_ID_BYTES)
+        buf = (C.c_uint8 * PD_COMM_ID_BYTES).from_buffer_copy(comm_id)
+        self._check(self.lib.pd_comm_init(self._h, buf, int(world), int(rank)))
+
+    def comm_world(self) -> Tuple[int, int]:
+        w, r = C.c_int32(), C.c_int32()
+        self._check(self.lib.pd_comm_world(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def comm_all_gather(self, latents):
+        """[b, ...] from every rank -> [world * b, ...] in rank order (equal b on every rank); the path's only exchange."""
+        world, _ = self.comm_world()
+        b = _Buf(latents)
+        self._order_after_torch(b.mem)
+        shape = (world * b.owner.shape[0],) + tuple(b.owner.shape[1:])
+        count = int(np.prod(b.owner.shape))
+        if b.mem == PD_MEM_DEVICE:
+            import torch
+            out = torch.empty(shape, dtype=torch.float32, device=b.owner.device)
+            self._check(self.lib.pd_comm_all_gather(self._h, b.ptr, out.data_ptr(), count, b.mem))
+        else:
+            out = np.empty(shape, np.float32)
+            self._check(self.lib.pd_comm_all_gather(self._h, b.ptr, out.ctypes.data, count, b.mem))
+        return out
+
+    def comm_destroy(self) -> None:
+        self._check(self.lib.pd_comm_destroy(self._h))
 
     # ------------------------------------------------------------------ instrumentation
     def synchronize(self):
