@@ -20,7 +20,9 @@ int main() {
     struct Shape { int B, H, Cin, Cout, res, ups, splitk; };
     const Shape shapes[] = {{16, 64, 320, 320, 1, 0, 1}, {16, 64, 320, 320, 0, 0, 1}, {16, 32, 640, 640, 1, 0, 1}, {16, 64, 640, 320, 1, 0, 1}, {16, 64, 960, 320, 1, 0, 1},
                             {16, 32, 1280, 640, 1, 0, 1}, {16, 32, 320, 640, 0, 0, 1}, {16, 16, 1280, 1280, 1, 0, 4}, {16, 16, 2560, 1280, 1, 0, 4}, {16, 16, 640, 1280, 0, 0, 2},
-                            {16, 64, 640, 640, 0, 1, 1}, {16, 32, 1280, 1280, 0, 1, 1}, {2, 64, 320, 320, 1, 0, 1}, {2, 32, 640, 640, 1, 0, 1}, {1, 16, 128, 324, 1, 0, 1}, {3, 16, 192, 40, 0, 1, 1}};
+                            {16, 64, 640, 640, 0, 1, 1}, {16, 32, 1280, 1280, 0, 1, 1}, {2, 64, 320, 320, 1, 0, 1}, {2, 32, 640, 640, 1, 0, 1}, {1, 16, 128, 324, 1, 0, 1}, {3, 16, 192, 40, 0, 1, 1},
+                            // M = 1024 (the 8x8 level's row count, as 4 images of 16x16): how would this kernel family do there, by split
+                            {4, 16, 1280, 1280, 1, 0, 4}, {4, 16, 1280, 1280, 1, 0, 5}, {4, 16, 1280, 1280, 1, 0, 10}, {4, 16, 2560, 1280, 1, 0, 8}, {4, 16, 2560, 1280, 1, 0, 10}};
     int bad = 0;
     for (const Shape& sh : shapes) {
         const int Hin = sh.ups ? sh.H / 2 : sh.H;
