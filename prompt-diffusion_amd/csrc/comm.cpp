@@ -97,7 +97,8 @@ int pd_comm_all_gather(pd_engine* e, const float* send, float* recv, int64_t cou
     const size_t bytes = (size_t)count * sizeof(float);
     if (!count) return 0;
     if (!e->comm) {
-        HIP_OK(hipMemcpyAsync(recv, send, bytes, mem == PD_MEM_HOST ? hipMemcpyHostToHost : hipMemcpyDeviceToDevice, e->stream));
+        if (mem == PD_MEM_HOST) { memcpy(recv, send, bytes); return 0; }
+        HIP_OK(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, e->stream));
         HIP_OK(hipStreamSynchronize(e->stream));
         return 0;
     }
