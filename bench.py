@@ -30,6 +30,20 @@ PEAK_F32_TFLOPS = 157.3
 GF_PER_FWD_SAMPLE_64 = 1067.5
 
 
+def shared_front_gf(h: int, w: int, fused_tail: bool = True) -> float:
+    """GF per CFG PAIR that option "cfg_share" does not execute (the layers in front of the first cross-attention run once for the
+    pair instead of twice; pd_engine::forward_eps): conv_in, the first ResBlock's two 3x3 convs, proj_in, to_q/k/v and the N x N
+    self-attention of the first SpatialTransformer, in the UNet and in the ControlNet, plus the ControlNet's first zero conv.  (With
+    the per-layer transformer path attn1.to_out and attn2.to_q are shared too; the fused tail kernel recomputes them per half.)"""
+    n, c = h * w, 320
+    conv_in = 2 * n * c * 9 * 4
+    res = 2 * (2 * n * c * 9 * c)
+    lin = 2 * n * c * c
+    attn = 4 * 8 * n * n * (c // 8)
+    per_net = conv_in + res + 4 * lin + attn + (0 if fused_tail else 2 * lin)
+    return (2 * per_net + lin) / 1e9
+
+
 def cpu_baseline(ddim_steps: int):
     """The oracle (NumPy restatement, kind 'port') timed on the host cores on a bounded sample of the same
     workload: ONE denoising step of ONE 512x512 image (CFG pair, latent 64x64); images/sec is
@@ -171,6 +185,8 @@ def main():
     ap.add_argument("--no-sd3", action="store_true", help="skip the SD3 / MMDiT leg (SURVEY N4 / BASELINE config #5, context only)")
     ap.add_argument("--engine-comm", action="store_true", help="N > 1: gather the final latents over the RCCL communicator the engine owns (pd_comm_*) instead of torch.distributed")
     ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=int (experiments)")
+    ap.add_argument("--no-cfg-share", action="store_true",
+                    help="run the layers in front of the first cross-attention on the doubled batch like the reference does (option cfg_share 0)")
     ap.add_argument("--single-stream", action="store_true",
                     help="serialise ControlNet and UNet on one stream in every pass (used for the committed rocprof summary, so\n"
                          "that per-kernel durations are not stretched by the concurrent kernel of the other stream)")
@@ -214,6 +230,8 @@ def main():
     eng.init_random_weights(1234 + rank)
     if args.single_stream:
         eng.set_option("two_streams", 0)
+    if args.no_cfg_share:
+        eng.set_option("cfg_share", 0)
     for o in args.opt:
         k, v = o.split("=")
         eng.set_option(k, int(v))
@@ -279,10 +297,34 @@ def main():
                    "stream_f32": bool(args.stream_f32), "controlnet_stream_overlap": not args.single_stream},
     }
     if rank == 0:
-        # whole-path MFMA fraction against the algorithmic (hoisted) FLOP count of SURVEY.md §8d
+        # whole-path MFMA fraction against the algorithmic (hoisted) FLOP count of SURVEY.md §8d -- minus, when the CFG pair's shared
+        # front ran once (stat cfg_shared), the contractions that were not executed: "stays in the denominator only if executed"
         gf_fwd = GF_PER_FWD_SAMPLE_64 * (h * w) / 4096.0 if (h, w) != (64, 64) else GF_PER_FWD_SAMPLE_64
-        tflop_image = 2 * S * gf_fwd / 1e3
+        shared = eng.stat("cfg_shared")
+        gf_saved_pair = shared_front_gf(h, w, fused_tail=args.precision in ("f16", "bf16") and not args.stream_f32) if shared == 3 else 0.0
+        tflop_image_ref = 2 * S * gf_fwd / 1e3
+        tflop_image = S * (2 * gf_fwd - gf_saved_pair) / 1e3
         result["path_tflops_per_gpu"] = value / world * tflop_image
+        result["cfg_shared_front"] = {
+            "on": shared == 3, "stat_cfg_shared": shared,
+            "what": "p_sample_ddim feeds cat([x]*2), cat([t]*2) and the same example pair / query to both halves of the CFG batch "
+                    "(ddim_hacked.py:189-192): the layers in front of the first cross-attention (conv_in, first ResBlock, first "
+                    "SpatialTransformer up to self-attention; UNet and ControlNet) are computed once per pair instead of twice. Exact: "
+                    "every layer still runs in every step on every distinct input; option cfg_share / --no-cfg-share turns it off",
+            "tflop_per_image_executed": tflop_image, "tflop_per_image_reference_count": tflop_image_ref,
+            "path_tflops_per_gpu_at_reference_count": value / world * tflop_image_ref}
+        if shared and world == 1:
+            # the same workload with the option off (1 warm-up + 1 timed pass, outside the metric's timed region)
+            eng.set_option("cfg_share", 0)
+            eng.ddim_sample(**kw)
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            o_off = eng.ddim_sample(**kw)
+            torch.cuda.synchronize()
+            dq = time.perf_counter() - tq
+            eng.set_option("cfg_share", 1)
+            result["cfg_shared_front"]["value_with_option_off"] = B / dq
+            result["cfg_shared_front"]["latents_shared_vs_doubled_max_rel"] = float((out[:B] - o_off).abs().max() / o_off.abs().max())
         if not args.no_profile:
             # one more pass with HIP events around every contraction launch (not part of the timed region).  It runs
             # single-stream: with ControlNet overlapped on the second stream two kernels share the chip and each one's

@@ -205,6 +205,11 @@ int pd_comm_destroy(pd_engine* e); /* also done by pd_engine_destroy */
 /* Tuning / instrumentation knobs (defaults are the measured best; tests and tools/ flip them for A/B runs):
  *   "verbose", "profile" (HIP events around every contraction launch, see pd_profile_read),
  *   "two_streams" (ControlNet on a second stream beside the UNet encoder, default 1),
+ *   "cfg_share" (classifier-free guidance feeds both halves of the doubled batch the same latent and timestep, ddim_hacked.py:189-192, and
+ *   -- unless pair_uncond / query_uncond say otherwise -- the same example pair and query: the layers in front of the first
+ *   cross-attention (conv_in, the first ResBlock, the first SpatialTransformer up to attn2.to_q, in the UNet and in the ControlNet)
+ *   run once on the B samples the halves have in common instead of twice; exact, default 1; stat "cfg_shared" tells whether the
+ *   last evaluation did: bit 0 UNet, bit 1 ControlNet),
  *   "graph" (pd_ddim_sample captures its step loop in a hipGraph and replays it on later calls with equal arguments, 0),
  *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "conv_patch2" (its wave-specialised second generation in the 2-byte modes, 1), "patch4" (the
  *   fourth generation -- 4 waves per block, one per SIMD, 32x32x16 MFMAs, LDS-DMA operands -- for every unsplit 2-byte patch conv, 1;
@@ -232,7 +237,7 @@ int pd_comm_destroy(pd_engine* e); /* also done by pd_engine_destroy */
  *   least this many 128-byte channel chunks per slice, 4). */
 int pd_set_option(pd_engine* e, const char* key, int64_t value);
 /* "workspace_bytes", "weight_bytes", "launches" (engine launches, split-K finalize passes not counted), "ring_launches" / "gn_from_slabs"
- * (of which: gemm_ring.hip / GroupNorm fed by split-K slabs), "steps", "event_overhead_ns" */
+ * (of which: gemm_ring.hip / GroupNorm fed by split-K slabs), "steps", "event_overhead_ns", "cfg_shared" (see option "cfg_share") */
 int64_t pd_get_stat(pd_engine* e, const char* key);
 /* Per-launch timing: while option "profile" is 1 the engine brackets every contraction launch with HIP
  * events on its stream.  klass 0 = igemm_kernel on a conv3x3, 1 = igemm_kernel / rgemm_kernel on a conv1x1/linear,

@@ -100,7 +100,7 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, void* __restrict_
 // ControlledUnetModel.forward (cldm/cldm.py:35,41) with the control residual adds folded in.
 __global__ void concat_add_kernel(const void* __restrict__ a, const void* __restrict__ a_add, const void* __restrict__ b,
                                   const void* __restrict__ b_add, void* __restrict__ out, int dt, long long rows, int Ca,
-                                  int Cb) {
+                                  int Cb, long long b_rows, long long b_add_rows) {
     const int C4 = (Ca + Cb) / 4;
     const long long total = rows * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -112,8 +112,10 @@ __global__ void concat_add_kernel(const void* __restrict__ a, const void* __rest
             x = load4(a, (size_t)r * Ca + c, dt);
             if (a_add) x += load4(a_add, (size_t)r * Ca + c, dt);
         } else {
-            x = load4(b, (size_t)r * Cb + (c - Ca), dt);
-            if (b_add) x += load4(b_add, (size_t)r * Cb + (c - Ca), dt);
+            // b / b_add may hold only the first b_rows / b_add_rows rows (tensors shared by the two halves of a CFG batch)
+            // (rows <= 2 * b_rows is checked by the launcher: one conditional subtraction instead of a 64-bit modulo)
+            x = load4(b, (size_t)(r >= b_rows ? r - b_rows : r) * Cb + (c - Ca), dt);
+            if (b_add) x += load4(b_add, (size_t)(r >= b_add_rows ? r - b_add_rows : r) * Cb + (c - Ca), dt);
         }
         store4(out, (size_t)r * (Ca + Cb) + c, dt, x);
     }
@@ -234,10 +236,13 @@ int launch_cast_rows(const float* in, void* out, int out_dt, long long rows, int
     CHECK_LAUNCH();
 }
 int launch_concat_add(const void* a, const void* a_add, const void* b, const void* b_add, void* out, int dt, long long rows,
-                      int Ca, int Cb, hipStream_t s) {
+                      int Ca, int Cb, hipStream_t s, long long b_rows, long long b_add_rows) {
     if (Ca % 4 || Cb % 4) return 1;
+    if (b_rows <= 0) b_rows = rows;
+    if (b_add_rows <= 0) b_add_rows = rows;
+    if (rows > 2 * b_rows || rows > 2 * b_add_rows) return 1;
     hipLaunchKernelGGL(concat_add_kernel, dim3(nblocks(rows * ((Ca + Cb) / 4), TPB, 8192)), dim3(TPB), 0, s, a, a_add, b, b_add,
-                       out, dt, rows, Ca, Cb);
+                       out, dt, rows, Ca, Cb, b_rows, b_add_rows);
     CHECK_LAUNCH();
 }
 int launch_add_inplace(void* a, const void* b, int dt, long long n, hipStream_t s) {

@@ -1003,9 +1003,18 @@ int pd_engine::resblock(const ResW& r, const Act& x, Act& out, const float* embr
 }
 
 // SpatialTransformer.forward + BasicTransformerBlock._forward, attention.py:321-340, :271-275
-int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv) {
-    const int B = x.B, H = x.H, W = x.W, C = s.C, N = H * W;
-    out = new_act(B, H, W, C, S);
+//
+// out_B > x.B (the shared front of a CFG batch, forward_eps): x holds the x.B samples both halves of the batch have in common -- the two
+// halves of cat([x] * 2) (ddim_hacked.py:189) are the same numbers until the first cross-attention reads their different contexts --
+// so GroupNorm, proj_in, norm1, attn1 (and, per layer, attn1.to_out, norm2, attn2.to_q) run once on x.B samples and the block's
+// output has out_B = 2 x.B: sample j of it continues from shared sample j % x.B with context j.
+int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv, int out_B) {
+    int B = x.B;
+    const int H = x.H, W = x.W, C = s.C, N = H * W;
+    if (out_B <= 0) out_B = B;
+    if (out_B % B) { pd_set_error("internal: transformer output batch %d over %d shared samples", out_B, B); return 1; }
+    const int reps = out_B / B;
+    out = new_act(out_B, H, W, C, S);
     const size_t mk = arena.mark();
     const bool fused = st_tail_on(s, N) && s.tail_w && s.front_w && kv.P;
     const int npad = round_up(N, 8);
@@ -1068,11 +1077,11 @@ int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& k
             ++launches;
             ProfRec rec{};
             if (profiling) {
-                prof_begin(rec, 4, st_tail_flops((long long)B * N, cfg.context_len));
-                rec.M = B * N; rec.N = C; rec.K = C; rec.taps = 0;
+                prof_begin(rec, 4, st_tail_flops((long long)out_B * N, cfg.context_len));
+                rec.M = out_B * N; rec.N = C; rec.K = C; rec.taps = 0;
             }
-            const int r = launch_st_tail(att.p, h.p, x.p, out.p, s.tail_w, s.tail_vec, kv.P, (long long)B * N, N, cfg.context_len, S,
-                                         (float)(1.0 / std::sqrt((double)(C / cfg.num_heads))), P, stream);
+            const int r = launch_st_tail(att.p, h.p, x.p, out.p, s.tail_w, s.tail_vec, kv.P, (long long)out_B * N, N, cfg.context_len, S,
+                                         (float)(1.0 / std::sqrt((double)(C / cfg.num_heads))), P, stream, (long long)B * N);
             if (profiling) prof_end(rec);
             if (r) { pd_set_error("fused transformer-tail launch failed: %s", hipGetErrorString(hipGetLastError())); return 1; }
         }
@@ -1086,18 +1095,42 @@ int pd_engine::transformer(const STW& s, const Act& x, Act& out, const KVSlot& k
     Act q2 = new_act(B, H, W, C, T);
     PD_TRY(gemm(s.q2, fuse ? h1 : ln, q2, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0, 0, nullptr, false, fuse ? &st1 : nullptr));
     const int L = cfg.context_len, lpad = round_up(L, 8);
+    Act xr = x;   // the block's residual at the output batch
+    if (reps > 1) {
+        // the shared queries meet each half's own context keys: one launch per half; from here on the batch is out_B
+        att = new_act(out_B, H, W, C, T);
+        for (int r = 0; r < reps; ++r)
+            PD_TRY(attention(q2.p, C, reinterpret_cast<const char*>(kv.K) + (size_t)r * B * L * C * eb, C,
+                             reinterpret_cast<const char*>(kv.VT) + (size_t)r * B * C * lpad * eb, lpad,
+                             reinterpret_cast<char*>(att.p) + (size_t)r * B * N * C * eb, C, B, N, L, C));
+        PD_TRY(repeat_act(h1, reps, h1));
+        PD_TRY(repeat_act(x, reps, xr));
+    } else
     PD_TRY(attention(q2.p, C, kv.K, C, kv.VT, lpad, att.p, C, B, N, L, C));
+    B = out_B;
     Act h2 = new_act(B, H, W, C, S);
     PD_TRY(gemm(s.out2, att, h2, 1, 0, 0, 1.f, &h1, nullptr, 0, false, nullptr, 0, 0));
     // GEGLU feed-forward (norm3 as a kernel: see fold_layernorms)
-    if (fuse) ln = new_act(B, H, W, C, T);
+    if (fuse || reps > 1) ln = new_act(B, H, W, C, T);
     PD_TRY(layernorm(h2, ln, s.ln_g[2], s.ln_b[2]));
     Act g = new_act(B, H, W, 4 * C, T);
     PD_TRY(gemm(s.ff1, ln, g, 1, 0, 0, 1.f, nullptr, nullptr, 0, false, nullptr, 0, 0));
     Act h3 = new_act(B, H, W, C, S);
     PD_TRY(gemm(s.ff2, g, h3, 1, 0, 0, 1.f, &h2, nullptr, 0, false, nullptr, 0, 0));
-    PD_TRY(conv(s.proj_out, h3, out, 0, 1.f, &x));
+    PD_TRY(conv(s.proj_out, h3, out, 0, 1.f, &xr));
     arena.release(mk);
+    return 0;
+}
+
+// `reps` copies of a tensor along the batch axis (the per-layer transformer path at the end of a shared CFG front)
+int pd_engine::repeat_act(const Act& src, int reps, Act& dst) {
+    Act d = new_act(src.B * reps, src.H, src.W, src.C, src.dt);
+    if (!arena.dry) {
+        PD_TRY(check_arena());
+        for (int r = 0; r < reps; ++r)
+            HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(d.p) + (size_t)r * src.bytes(), src.p, src.bytes(), hipMemcpyDeviceToDevice, stream));
+    }
+    dst = d;
     return 0;
 }
 
@@ -1108,15 +1141,19 @@ static const float* emb_ptr(const std::vector<float*>& tabs, const ResW& r, int 
 
 // ControlNet.forward, cldm/cldm.py:302-325 (hint embedders hoisted into the session: they do not
 // depend on the timestep); outputs go to ses.control[] already multiplied by control_scales (:379).
-int pd_engine::run_controlnet(const Act& x_in, int emb_row, int emb_stride, const float* scales) {
+int pd_engine::run_controlnet(const Act& x_in_full, int emb_row, int emb_stride, const float* scales) {
     NetW& n = cnet;
     Act h;
+    // shared CFG front (forward_eps): until the first transformer block the network runs on the samples the two halves have in common
+    const int Bf = x_in_full.B;
+    Act x_in = x_in_full, hint = ses.hint;
+    if (ses.share_c) { x_in.B = Bf / 2; hint.B = Bf / 2; }
     for (size_t i = 0; i < n.enc.size(); ++i) {
         EncBlock& b = n.enc[i];
         Act o;
         if (b.kind == 0) {
             o = new_act(x_in.B, x_in.H, x_in.W, b.cout, S);
-            PD_TRY(conv(b.conv, x_in, o, 0, 1.f, &ses.hint));  // h = conv_in(x) + guided_hint, :315-317
+            PD_TRY(conv(b.conv, x_in, o, 0, 1.f, &hint));  // h = conv_in(x) + guided_hint, :315-317
         } else if (b.kind == 2) {
             o = new_act(h.B, h.H / 2, h.W / 2, b.cout, S);
             PD_TRY(conv(b.conv, h, o));
@@ -1124,16 +1161,17 @@ int pd_engine::run_controlnet(const Act& x_in, int emb_row, int emb_stride, cons
             PD_TRY(resblock(b.res, h, o, emb_ptr(ses.emb_c, b.res, emb_row), emb_stride ? b.res.cout : 0));
             if (b.attn) {
                 Act o2;
-                PD_TRY(transformer(b.st, o, o2, ses.kv_c[b.st.kv_slot]));
+                PD_TRY(transformer(b.st, o, o2, ses.kv_c[b.st.kv_slot], Bf));
                 o = o2;
             }
         }
         h = o;
+        if (ses.control[i].B != h.B) { pd_set_error("internal: control tensor %d sized for batch %d, block output has %d", (int)i, ses.control[i].B, h.B); return 1; }
         PD_TRY(conv(n.zero[i], h, ses.control[i], 0, scales ? scales[i] : 1.f));
     }
     Act m0, m1, m2;
     PD_TRY(resblock(n.mid0, h, m0, emb_ptr(ses.emb_c, n.mid0, emb_row), emb_stride ? n.mid0.cout : 0));
-    PD_TRY(transformer(n.mid1, m0, m1, ses.kv_c[n.mid1.kv_slot]));
+    PD_TRY(transformer(n.mid1, m0, m1, ses.kv_c[n.mid1.kv_slot], Bf));
     PD_TRY(resblock(n.mid2, m1, m2, emb_ptr(ses.emb_c, n.mid2, emb_row), emb_stride ? n.mid2.cout : 0));
     const int last = (int)n.enc.size();
     PD_TRY(conv(n.mid_out, m2, ses.control[last], 0, scales ? scales[last] : 1.f));
@@ -1141,10 +1179,13 @@ int pd_engine::run_controlnet(const Act& x_in, int emb_row, int emb_stride, cons
 }
 
 // ControlledUnetModel.forward, cldm/cldm.py:23-45
-int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_mid, Act& eps) {
+int pd_engine::run_unet(const Act& x_in_full, int emb_row, int emb_stride, bool only_mid, Act& eps) {
     NetW& n = unet;
     std::vector<Act> hs;
     Act h;
+    const int Bf = x_in_full.B;
+    Act x_in = x_in_full;
+    if (ses.share_u) x_in.B = Bf / 2;   // shared CFG front, as in run_controlnet; the skip tensors of the front stay at half batch
     for (size_t i = 0; i < n.enc.size(); ++i) {
         EncBlock& b = n.enc[i];
         Act o;
@@ -1158,7 +1199,7 @@ int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_
             PD_TRY(resblock(b.res, h, o, emb_ptr(ses.emb_u, b.res, emb_row), emb_stride ? b.res.cout : 0));
             if (b.attn) {
                 Act o2;
-                PD_TRY(transformer(b.st, o, o2, ses.kv_u[b.st.kv_slot]));
+                PD_TRY(transformer(b.st, o, o2, ses.kv_u[b.st.kv_slot], Bf));
                 o = o2;
             }
         }
@@ -1167,7 +1208,7 @@ int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_
     }
     Act m0, m1, m2;
     PD_TRY(resblock(n.mid0, h, m0, emb_ptr(ses.emb_u, n.mid0, emb_row), emb_stride ? n.mid0.cout : 0));
-    PD_TRY(transformer(n.mid1, m0, m1, ses.kv_u[n.mid1.kv_slot]));
+    PD_TRY(transformer(n.mid1, m0, m1, ses.kv_u[n.mid1.kv_slot], Bf));
     PD_TRY(resblock(n.mid2, m1, m2, emb_ptr(ses.emb_u, n.mid2, emb_row), emb_stride ? n.mid2.cout : 0));
     h = m2;
     PD_TRY(join_controlnet());   // the decoder is the first consumer of the control tensors
@@ -1184,7 +1225,7 @@ int pd_engine::run_unet(const Act& x_in, int emb_row, int emb_stride, bool only_
             PD_TRY(check_arena());
             ++launches;
             if (launch_concat_add(h.p, a_add ? a_add->p : nullptr, skip.p, b_add ? b_add->p : nullptr, cat.p, S, h.rows(), h.C,
-                                  skip.C, stream)) {
+                                  skip.C, stream, skip.rows(), b_add ? b_add->rows() : 0)) {
                 pd_set_error("concat launch failed");
                 return 1;
             }
@@ -1237,11 +1278,24 @@ int pd_engine::forward_eps(int emb_row, int emb_stride, const float* scales, Act
     const int Bf = ses.Bf;
     Act x_in;
     x_in.p = ses.x_in; x_in.B = Bf; x_in.H = a.h; x_in.W = a.w; x_in.C = 8; x_in.dt = DT_F32;
+    // Shared CFG front.  p_sample_ddim runs the networks on cat([x] * 2), cat([t] * 2) and [unconditional ; conditional] conditioning
+    // (ddim_hacked.py:189-192): sample j and sample B + j enter with the same latent and the same timestep, and, unless the caller
+    // gave the unconditional half its own example pair / query, the same guided_hint.  Until the first cross-attention reads the two
+    // contexts, both halves therefore carry the same numbers, and the engine computes them once: conv_in, the first ResBlock, and the
+    // first SpatialTransformer up to attn2.to_q run on B samples (pd_engine::transformer's out_B), their skip / control tensors stay at
+    // B samples and are read twice.  Exact; what differs is only which tile shapes a half-size launch picks.  Needs the time embedding of a
+    // step to be one row for the whole batch (emb_stride 0: the sampler's own calls).  Guess mode zeroes the unconditional half of every
+    // control tensor (join_controlnet) and keeps the ControlNet unshared.
+    const bool share = opt_cfg_share && a.use_cfg && emb_stride == 0 && Bf % 2 == 0;
+    ses.share_u = share;
+    ses.share_c = share && ses.hint_shared && !a.guess_mode;
     // the 13 control tensors outlive the ControlNet pass
     int hh = a.h, ww = a.w;
+    bool front = ses.share_c;
     for (size_t i = 0; i < cnet.enc.size(); ++i) {
         if (cnet.enc[i].kind == 2) { hh /= 2; ww /= 2; }
-        ses.control[i] = new_act(Bf, hh, ww, cnet.enc[i].cout, S);
+        if (cnet.enc[i].attn) front = false;
+        ses.control[i] = new_act(front ? Bf / 2 : Bf, hh, ww, cnet.enc[i].cout, S);
     }
     ses.control[cnet.enc.size()] = new_act(Bf, hh, ww, cnet.enc.back().cout, S);
     // ControlNet and the UNet encoder + middle block are independent: ControlNet is enqueued on a second stream with its

@@ -245,6 +245,9 @@ struct Session {
     float* per_step = nullptr;  // optional [S+1][B,C,h,w]
     Act control[PD_NUM_CONTROL];
     size_t session_top = 0;
+    // shared CFG front (pd_engine::forward_eps): both halves of the batch see the same guided_hint; this evaluation runs the UNet's /
+    // the ControlNet's layers in front of the first cross-attention once for both halves
+    bool hint_shared = false, share_u = false, share_c = false;
 };
 
 struct pd_engine {
@@ -282,6 +285,7 @@ struct pd_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool cn_pending = false;
     bool opt_two_streams = true;
+    bool opt_cfg_share = true;   // option "cfg_share": the layers in front of the first cross-attention once per CFG pair (forward_eps)
     void swap_context();
     int join_controlnet();
     Session ses;
@@ -405,7 +409,8 @@ struct pd_engine {
     int groupnorm(const Act& x, Act& y, const float* g, const float* b, float eps, bool silu, const SlabDefer* from_slabs = nullptr);
     int layernorm(const Act& x, Act& y, const float* g, const float* b);
     int resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride);
-    int transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv);
+    int transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv, int out_B = 0);
+    int repeat_act(const Act& src, int reps, Act& dst);
     int attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B, int Nq,
                   int Nk, int C, int heads = 0, bool causal = false, long long q_bs = 0, long long k_bs = 0, long long o_bs = 0);
 

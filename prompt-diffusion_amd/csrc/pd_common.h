@@ -256,7 +256,7 @@ int launch_st_tail_vec(const float* bo1, const float* bq_ln, const float* bo2, c
                        hipStream_t s);
 int launch_st_tail_kv_pack(const void* K, const void* VT, void* dst, int B, int Nk, int lpad, hipStream_t s);
 int launch_st_tail(const void* att, const void* h, const void* x_in, void* out, const void* wpk, const float* vec, const void* kvp, long long M,
-                   int rows_per_sample, int Nk, int s_dt, float scale, int prec, hipStream_t s);
+                   int rows_per_sample, int Nk, int s_dt, float scale, int prec, hipStream_t s, long long in_rows = 0);
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
                     const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s);
@@ -286,7 +286,7 @@ int launch_embed_tokens(const int* ids, const void* tok, int tok_ld, const void*
 int launch_nhwc_to_nchw(const void* in, int in_dt, float* out, int B, int C, int H, int W, int Cpad, float scale, hipStream_t s);
 int launch_cast_rows(const float* in, void* out, int out_dt, long long rows, int C, int Cpad, hipStream_t s);
 int launch_concat_add(const void* a, const void* a_add, const void* b, const void* b_add, void* out, int dt,
-                      long long rows, int Ca, int Cb, hipStream_t s);
+                      long long rows, int Ca, int Cb, hipStream_t s, long long b_rows = 0, long long b_add_rows = 0);
 int launch_add_inplace(void* a, const void* b, int dt, long long n, hipStream_t s);
 struct DdimCoef { float sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma, cfg_scale; };
 int launch_cfg_ddim(const void* eps, int eps_dt, int eps_C, float* x_state, float* pred_x0, float* eps_guided,

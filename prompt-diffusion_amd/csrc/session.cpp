@@ -199,6 +199,7 @@ int pd_engine::session_setup(const pd_sample_args& a, const int64_t* t_rows, int
     // ---- guided_hint = input_hint_block(pair) + input_cond_block(query), cldm/cldm.py:306-308
     {
         Act prev_out;
+        s.hint_shared = a.use_cfg != 0;
         for (int which = 0; which < 2; ++which) {
             const int cin = which == 0 ? cfg.hint_channels : cfg.query_channels;
             const float* src_c = which == 0 ? a.pair : a.query;
@@ -207,6 +208,7 @@ int pd_engine::session_setup(const pd_sample_args& a, const int64_t* t_rows, int
             Act img = new_act(Bf, IH, IW, 8, T);
             const float* dc = stage(src_c, per);
             const float* du = (a.use_cfg && src_u != src_c) ? stage(src_u, per) : dc;
+            if (src_u != src_c) s.hint_shared = false;
             if (!arena.dry) {
                 char* dst = reinterpret_cast<char*>(img.p);
                 const size_t half = (size_t)B * IH * IW * 8 * dt_size(T);
@@ -396,7 +398,7 @@ int pd_engine::run_steps_graph() {
     const pd_sample_args& a = ses.a;
     uint64_t key = 1469598103934665603ull;
     const int32_t ints[] = {a.batch, a.h, a.w, a.steps, a.use_cfg, a.guess_mode, a.only_mid_control, ses.noise ? 1 : 0,
-                            ses.per_step ? 1 : 0, opt_two_streams ? 1 : 0, ses.S};
+                            ses.per_step ? 1 : 0, opt_two_streams ? 1 : 0, ses.S, opt_cfg_share ? 1 : 0};
     const float flts[] = {a.eta, a.cfg_scale, a.temperature};
     const void* ptrs[] = {arena.base, arena2.base, ses.x_state, ses.per_step};
     hash_mix(key, ints, sizeof(ints));
@@ -753,6 +755,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "ln_fuse")) { e->opt_ln_fuse = (int)value; e->ln_dirty = true; return 0; }
     if (!strcmp(key, "st_fuse")) { e->opt_st_fuse = value != 0; e->ln_dirty = true; return 0; }
     if (!strcmp(key, "two_streams")) { e->opt_two_streams = value != 0; return 0; }
+    if (!strcmp(key, "cfg_share")) { e->opt_cfg_share = value != 0; return 0; }
     if (!strcmp(key, "wide_tile")) { e->opt_wide = value != 0; return 0; }
     if (!strcmp(key, "slab_gn")) { e->opt_slab_gn = (int)value; return 0; }
     if (!strcmp(key, "ring")) { e->opt_ring = (int)value; return 0; }
@@ -811,6 +814,7 @@ int64_t pd_get_stat(pd_engine* e, const char* key) {
     if (!strcmp(key, "gn_from_slabs")) return (int64_t)e->gn_from_slabs;
     if (!strcmp(key, "ring_launches")) return (int64_t)e->ring_launches;   // of which: gemm_ring.hip's persistent ring kernel
     if (!strcmp(key, "steps")) return (int64_t)e->ses.S;
+    if (!strcmp(key, "cfg_shared")) return (int64_t)((e->ses.share_u ? 1 : 0) | (e->ses.share_c ? 2 : 0));
     if (!strcmp(key, "event_overhead_ns")) return (int64_t)(e->prof_overhead_ms * 1e6f);
     return -1;
 }

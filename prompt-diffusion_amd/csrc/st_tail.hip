@@ -117,6 +117,7 @@ struct StTailArgs {
     const char* kvp;      // [B][4][KV_PAIR] fragments
     int rows_per_sample, Nk;
     float scale_log2e;    // dh^-0.5 * log2(e)
+    int in_rows;          // att / h / x_in hold this many rows; output row r reads input row r % in_rows (the shared front of a CFG pair: pd_engine::transformer)
 };
 
 // front kernel (GroupNorm apply + proj_in + norm1 + to_q/k/v): [proj_in 200 | qkv 600] fragments, a linear stream of 40 steps
@@ -263,6 +264,13 @@ __global__ __launch_bounds__(256, 1) void st_tail_kernel(StTailArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5;
     const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    {   // inputs shared by the two halves of a CFG batch: a workgroup of the second half reads the first half's rows (scalar pointer offset)
+        const unsigned blk0 = blockIdx.x * 128u;
+        const long long back = (long long)(blk0 - blk0 % (unsigned)a.in_rows);
+        a.att = reinterpret_cast<const char*>(a.att) - back * TC * (long long)sizeof(uint16_t);
+        a.h = reinterpret_cast<const char*>(a.h) - back * TC * (long long)(SF32 ? 4 : 2);
+        a.x_in = reinterpret_cast<const char*>(a.x_in) - back * TC * (long long)(SF32 ? 4 : 2);
+    }
 
     PD_STAMP_AT(0);
     Pipe<0> pp;
@@ -822,10 +830,11 @@ int launch_st_tail_kv_pack(const void* K, const void* VT, void* dst, int B, int 
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int launch_st_tail(const void* att, const void* h, const void* x_in, void* out, const void* wpk, const float* vec, const void* kvp, long long M,
-                   int rows_per_sample, int Nk, int s_dt, float scale, int prec, hipStream_t s) {
-    if (M % 128 || rows_per_sample % 128 || Nk < 1 || Nk > 96) return 1;
+                   int rows_per_sample, int Nk, int s_dt, float scale, int prec, hipStream_t s, long long in_rows) {
+    if (in_rows <= 0) in_rows = M;
+    if (M % 128 || M > 0x7fffffff || rows_per_sample % 128 || Nk < 1 || Nk > 96 || in_rows % 128 || M % in_rows) return 1;
     StTailArgs a{att, h, x_in, out, reinterpret_cast<const char*>(wpk), vec, reinterpret_cast<const char*>(kvp), rows_per_sample, Nk,
-                 scale * 1.4426950408889634f};
+                 scale * 1.4426950408889634f, (int)in_rows};
     constexpr int SMEM = RING_BYTES + V_TOTAL * 4;
     static unsigned long long done[2] = {0, 0};
     if (s_dt != prec) return 1;   // the stream type is the compute type here (option stream_f32 keeps the per-layer path: an fp32 stream's
