@@ -313,7 +313,7 @@ def main():
                     "every layer still runs in every step on every distinct input; option cfg_share / --no-cfg-share turns it off",
             "tflop_per_image_executed": tflop_image, "tflop_per_image_reference_count": tflop_image_ref,
             "path_tflops_per_gpu_at_reference_count": value / world * tflop_image_ref}
-        if shared and world == 1:
+        if shared and world == 1 and not args.no_f32:
             # the same workload with the option off (1 warm-up + 1 timed pass, outside the metric's timed region)
             eng.set_option("cfg_share", 0)
             eng.ddim_sample(**kw)
