@@ -361,6 +361,11 @@ def main():
                 classes["igemm+rgemm_kernel[linear, K<=1280: HBM view]"] = dict(
                     ms=ms_s, launches=len(rows), avg_us=1e3 * ms_s / len(rows), algorithmic_gb_per_s=by / ms_s / 1e6,
                     frac_of_8_tb_s=by / ms_s / 1e6 / 8000.0)
+            # cross-check of the FLOP accounting: what the engine's own per-launch records add up to for this pass (every contraction
+            # launch, 2*M*N*K with logical channel counts; the hoisted per-call setup included) against the analytic executed count
+            _, n_all, fl_all = eng.profile_read(-1)
+            result["cfg_shared_front"]["tflop_per_image_recorded_by_engine"] = fl_all / 1e12 / B
+            result["cfg_shared_front"]["contraction_launches_per_pass"] = n_all
             eng.set_option("profile", 0)
             eng.set_option("two_streams", 0 if args.single_stream else 1)
             # dominant kernel family by device time: the generic contraction kernels -- igemm_kernel (every instantiation: linear /
