@@ -209,7 +209,8 @@ int pd_comm_destroy(pd_engine* e); /* also done by pd_engine_destroy */
  *   -- unless pair_uncond / query_uncond say otherwise -- the same example pair and query: the layers in front of the first
  *   cross-attention (conv_in, the first ResBlock, the first SpatialTransformer up to attn2.to_q, in the UNet and in the ControlNet)
  *   run once on the B samples the halves have in common instead of twice; exact, default 1; stat "cfg_shared" tells whether the
- *   last evaluation did: bit 0 UNet, bit 1 ControlNet),
+ *   last evaluation did: bit 0 UNet, bit 1 ControlNet; bit 2: guess mode under guidance ran the ControlNet on the conditional half only,
+ *   as pipeline_prompt_diffusion.py:1220-1224 does, instead of on the doubled batch with the unconditional residuals zeroed afterwards),
  *   "graph" (pd_ddim_sample captures its step loop in a hipGraph and replays it on later calls with equal arguments, 0),
  *   "conv_patch" (LDS-patch conv3x3 kernel, 1), "conv_patch2" (its wave-specialised second generation in the 2-byte modes, 1), "patch4" (the
  *   fourth generation -- 4 waves per block, one per SIMD, 32x32x16 MFMAs, LDS-DMA operands -- for every unsplit 2-byte patch conv, 1;

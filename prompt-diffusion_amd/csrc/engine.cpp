@@ -1145,9 +1145,30 @@ int pd_engine::run_controlnet(const Act& x_in_full, int emb_row, int emb_stride,
     NetW& n = cnet;
     Act h;
     // shared CFG front (forward_eps): until the first transformer block the network runs on the samples the two halves have in common
-    const int Bf = x_in_full.B;
+    int Bf = x_in_full.B;
     Act x_in = x_in_full, hint = ses.hint;
     if (ses.share_c) { x_in.B = Bf / 2; hint.B = Bf / 2; }
+    // guess mode under guidance ((D) pipeline :1220-1224, :1248-1253): the ControlNet sees the conditional half only and the unconditional
+    // half gets zero residuals.  The network runs on views of the second half of the batch (latents, guided_hint, context K / V^T, control
+    // tensors); join_controlnet zeroes the first half of every control tensor.
+    const int s0 = ses.cn_cond_only ? Bf / 2 : 0;   // first sample of the views
+    if (s0) {
+        Bf -= s0;
+        x_in = batch_view(x_in_full, s0, Bf);
+        hint = batch_view(ses.hint, s0, Bf);
+    }
+    auto kvs = [&](const STW& st) {
+        KVSlot k = ses.kv_c[st.kv_slot];
+        if (s0) {
+            const size_t eb = dt_size(T);
+            const int L = cfg.context_len, lpad = round_up(L, 8);
+            k.K = reinterpret_cast<char*>(k.K) + (size_t)s0 * L * st.C * eb;
+            k.VT = reinterpret_cast<char*>(k.VT) + (size_t)s0 * st.C * lpad * eb;
+            if (k.P) k.P = reinterpret_cast<char*>(k.P) + st_tail_kv_bytes(s0);
+        }
+        return k;
+    };
+    auto ctl = [&](int i) { return s0 ? batch_view(ses.control[i], s0, Bf) : ses.control[i]; };
     for (size_t i = 0; i < n.enc.size(); ++i) {
         EncBlock& b = n.enc[i];
         Act o;
@@ -1161,21 +1182,31 @@ int pd_engine::run_controlnet(const Act& x_in_full, int emb_row, int emb_stride,
             PD_TRY(resblock(b.res, h, o, emb_ptr(ses.emb_c, b.res, emb_row), emb_stride ? b.res.cout : 0));
             if (b.attn) {
                 Act o2;
-                PD_TRY(transformer(b.st, o, o2, ses.kv_c[b.st.kv_slot], Bf));
+                PD_TRY(transformer(b.st, o, o2, kvs(b.st), Bf));
                 o = o2;
             }
         }
         h = o;
-        if (ses.control[i].B != h.B) { pd_set_error("internal: control tensor %d sized for batch %d, block output has %d", (int)i, ses.control[i].B, h.B); return 1; }
-        PD_TRY(conv(n.zero[i], h, ses.control[i], 0, scales ? scales[i] : 1.f));
+        Act c = ctl((int)i);
+        if (c.B != h.B) { pd_set_error("internal: control tensor %d sized for batch %d, block output has %d", (int)i, c.B, h.B); return 1; }
+        PD_TRY(conv(n.zero[i], h, c, 0, scales ? scales[i] : 1.f));
     }
     Act m0, m1, m2;
     PD_TRY(resblock(n.mid0, h, m0, emb_ptr(ses.emb_c, n.mid0, emb_row), emb_stride ? n.mid0.cout : 0));
-    PD_TRY(transformer(n.mid1, m0, m1, ses.kv_c[n.mid1.kv_slot], Bf));
+    PD_TRY(transformer(n.mid1, m0, m1, kvs(n.mid1), Bf));
     PD_TRY(resblock(n.mid2, m1, m2, emb_ptr(ses.emb_c, n.mid2, emb_row), emb_stride ? n.mid2.cout : 0));
     const int last = (int)n.enc.size();
-    PD_TRY(conv(n.mid_out, m2, ses.control[last], 0, scales ? scales[last] : 1.f));
+    Act cl = ctl(last);
+    PD_TRY(conv(n.mid_out, m2, cl, 0, scales ? scales[last] : 1.f));
     return 0;
+}
+
+// samples [first, first + count) of a batched tensor
+Act pd_engine::batch_view(const Act& a, int first, int count) {
+    Act v = a;
+    v.p = reinterpret_cast<char*>(a.p) + (size_t)first * a.H * a.W * a.C * dt_size(a.dt);
+    v.B = count;
+    return v;
 }
 
 // ControlledUnetModel.forward, cldm/cldm.py:23-45
@@ -1289,6 +1320,7 @@ int pd_engine::forward_eps(int emb_row, int emb_stride, const float* scales, Act
     const bool share = opt_cfg_share && a.use_cfg && emb_stride == 0 && Bf % 2 == 0;
     ses.share_u = share;
     ses.share_c = share && ses.hint_shared && !a.guess_mode;
+    ses.cn_cond_only = opt_cfg_share && a.guess_mode && a.use_cfg && emb_stride == 0 && Bf % 2 == 0;
     // the 13 control tensors outlive the ControlNet pass
     int hh = a.h, ww = a.w;
     bool front = ses.share_c;

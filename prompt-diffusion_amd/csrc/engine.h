@@ -248,6 +248,7 @@ struct Session {
     // shared CFG front (pd_engine::forward_eps): both halves of the batch see the same guided_hint; this evaluation runs the UNet's /
     // the ControlNet's layers in front of the first cross-attention once for both halves
     bool hint_shared = false, share_u = false, share_c = false;
+    bool cn_cond_only = false;   // guess mode under guidance: this evaluation runs the ControlNet on the conditional half only (run_controlnet)
 };
 
 struct pd_engine {
@@ -411,6 +412,7 @@ struct pd_engine {
     int resblock(const ResW& r, const Act& x, Act& out, const float* embrow, int emb_stride);
     int transformer(const STW& s, const Act& x, Act& out, const KVSlot& kv, int out_B = 0);
     int repeat_act(const Act& src, int reps, Act& dst);
+    static Act batch_view(const Act& a, int first, int count);
     int attention(const void* Q, int ldq, const void* K, int ldk, const void* VT, int vt_ld, void* O, int ldo, int B, int Nq,
                   int Nk, int C, int heads = 0, bool causal = false, long long q_bs = 0, long long k_bs = 0, long long o_bs = 0);
 

@@ -814,7 +814,7 @@ int64_t pd_get_stat(pd_engine* e, const char* key) {
     if (!strcmp(key, "gn_from_slabs")) return (int64_t)e->gn_from_slabs;
     if (!strcmp(key, "ring_launches")) return (int64_t)e->ring_launches;   // of which: gemm_ring.hip's persistent ring kernel
     if (!strcmp(key, "steps")) return (int64_t)e->ses.S;
-    if (!strcmp(key, "cfg_shared")) return (int64_t)((e->ses.share_u ? 1 : 0) | (e->ses.share_c ? 2 : 0));
+    if (!strcmp(key, "cfg_shared")) return (int64_t)((e->ses.share_u ? 1 : 0) | (e->ses.share_c ? 2 : 0) | (e->ses.cn_cond_only ? 4 : 0));
     if (!strcmp(key, "event_overhead_ns")) return (int64_t)(e->prof_overhead_ms * 1e6f);
     return -1;
 }
