@@ -218,7 +218,8 @@ int pd_comm_destroy(pd_engine* e); /* also done by pd_engine_destroy */
  *   split over 2-4 slices when it has fewer tiles than CUs but at least this many, 1 / 64), "gn_fuse" (GroupNorm applied while the patch is staged, 0),
  *   "ln_fuse" (norm1 / norm2 of a transformer block folded into the to_q/k/v and attn2.to_q GEMMs, row statistics carried
  *   from the producing GEMM's epilogue: -1 = on in the 2-byte modes and off in the fp32-storage modes, 0 / 1 forced),
- *   "gn_single" (single-kernel LDS-slab GroupNorm where a sample's group bundle fits, 1),
+ *   "gn_single" (single-kernel LDS-slab GroupNorm where a sample's group bundle fits, 1), "gn_reg" (process-wide: its register-resident
+ *   form -- one block per (sample, group), the group's slab in registers, one barrier -- for 2-byte tensors of 64 / 256 / 1024 pixels, 1),
  *   "big_tile" / "wide_tile" (256x160 / 256x320 GEMM tiles, 1), "dense_k" / "dense_tiles" (8-wave unsplit tile for
  *   linear layers with at most that many K steps, 40 / 128), "short_k" (8-wave 128x160 tile at 16 waves per CU for
  *   linear layers with at most that many K steps, 20), "splitk_tiles" (split K below this many tiles, 384),

@@ -11,6 +11,8 @@
 
 #include "pd_common.h"
 
+int g_gn_reg = 1;   // option "gn_reg": the register-resident single-kernel GroupNorm where it applies (process-wide)
+
 namespace {
 
 constexpr int GN_THREADS = 256;
@@ -472,6 +474,156 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const void* __restrict__ W
 }
 
 // calls f(integral_constant<XD>, integral_constant<YD>) for the (input, output) type pairs the engine produces:
+
+// Register-resident single-kernel GroupNorm (round 4) for the 2-byte modes: ONE block per (sample, group), the group's HW x cpg slab
+// lives in the block's registers -- thread (pr, v) owns vector v (VB bytes = VB / 2 channels) of the pixels pr + 64 i, i < NL = HW / 64 --
+// so every load is issued before the first use, there is no LDS slab and one barrier (the wave partials).  gn_fused_kernel above takes
+// 15-16 us on a 2.6 MB tensor (the 8x8 level): 960-thread blocks, an LDS round trip and two barriers, whatever the size.  Statistics
+// as there: fp32 runs of at most 16 values per (thread, channel), fp64 from then on, fixed order (bit-reproducible).  SLAB: the input is
+// rebuilt from a split-K GEMM's fp32 slabs in splitk_finalize_kernel's order and rounding (see GnSlabSrc).
+template <int XD, int VB, int NL, bool SLAB>
+__global__ __launch_bounds__(NL == 16 ? 512 : 1024) void gn_reg_kernel(const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int HW, int C, int groups, int nv, float eps,
+                                                       int do_silu, GnSlabSrc src) {
+    constexpr int EV = VB / 2;           // channels per vector
+    constexpr int NW = VB / 4;           // dwords per vector
+    __shared__ double red[16][2];
+    int bid = blockIdx.x;
+    {   // consecutive groups of a sample (they share 128-byte lines) on the same XCD: blocks b and b + 8 share an L2
+        const int total = gridDim.x, q = total >> 3, r = total & 7, xk = bid & 7;
+        bid = (xk < r ? xk * (q + 1) : r * (q + 1) + (xk - r) * q) + (bid >> 3);
+    }
+    const int b = bid / groups, g = bid - b * groups;
+    const int tid = threadIdx.x;
+    const int v = tid % nv, pr = tid / nv;          // pr < 64
+    const int cpg = C / groups;
+    const int c0 = g * cpg + v * EV;
+    unsigned raw[NL][NW];
+    const char* xb = reinterpret_cast<const char*>(x) + ((size_t)b * HW * C + c0) * 2;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int p = pr + 64 * i;
+        if constexpr (SLAB) {
+            static_assert(!SLAB || EV >= 4, "slab input comes in 4-channel pieces");
+            const float* sp = src.slabs + ((size_t)b * HW + p) * C + c0;
+            float acc[EV];
+#pragma unroll
+            for (int j = 0; j < EV; j += 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(sp + j);
+                for (int k = 1; k < src.nslab; ++k) t += *reinterpret_cast<const f32x4*>(sp + (size_t)k * src.slab_stride + j);
+                if (src.bias) t += *reinterpret_cast<const f32x4*>(src.bias + c0 + j);
+                if (src.row) t += *reinterpret_cast<const f32x4*>(src.row + (size_t)b * src.row_stride + c0 + j);
+                acc[j] = t[0]; acc[j + 1] = t[1]; acc[j + 2] = t[2]; acc[j + 3] = t[3];
+            }
+#pragma unroll
+            for (int w = 0; w < NW; ++w) raw[i][w] = pack2<XD>(acc[2 * w], acc[2 * w + 1]);
+        } else {
+            const char* q = xb + (size_t)p * C * 2;
+            if constexpr (NW == 4) {
+                const uint4 t = *reinterpret_cast<const uint4*>(q);
+                raw[i][0] = t.x; raw[i][1] = t.y; raw[i][2] = t.z; raw[i][3] = t.w;
+            } else if constexpr (NW == 2) {
+                const uint2 t = *reinterpret_cast<const uint2*>(q);
+                raw[i][0] = t.x; raw[i][1] = t.y;
+            } else {
+                raw[i][0] = *reinterpret_cast<const unsigned*>(q);
+            }
+        }
+    }
+    // per-(thread, channel) fp32 sums over NL <= 16 values, then fp64
+    float s[EV], q2[EV];
+#pragma unroll
+    for (int j = 0; j < EV; ++j) { s[j] = 0.f; q2[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            float lo, hi;
+            unpack2<XD>(raw[i][w], lo, hi);
+            s[2 * w] += lo; q2[2 * w] = fmaf(lo, lo, q2[2 * w]);
+            s[2 * w + 1] += hi; q2[2 * w + 1] = fmaf(hi, hi, q2[2 * w + 1]);
+        }
+    double gs = 0.0, gq = 0.0;
+#pragma unroll
+    for (int j = 0; j < EV; ++j) { gs += (double)s[j]; gq += (double)q2[j]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = gs; red[tid >> 6][1] = gq; }
+    __syncthreads();
+    double S = 0.0, Q = 0.0;
+    for (int t = 0; t < nv; ++t) { S += red[t][0]; Q += red[t][1]; }   // 64 nv threads = nv waves, in wave order
+    const double n = (double)HW * (double)cpg;
+    const double mean = S / n;
+    double var = Q / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean_f = (float)mean, rstd_f = (float)(1.0 / sqrt(var + (double)eps));
+    float ka[EV], kb[EV];
+#pragma unroll
+    for (int j = 0; j < EV; ++j) {
+        ka[j] = rstd_f * gamma[c0 + j];
+        kb[j] = beta[c0 + j] - mean_f * ka[j];
+    }
+    char* yb = reinterpret_cast<char*>(y) + ((size_t)b * HW * C + c0) * 2;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        unsigned out[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            float lo, hi;
+            unpack2<XD>(raw[i][w], lo, hi);
+            float r0 = fmaf(lo, ka[2 * w], kb[2 * w]), r1 = fmaf(hi, ka[2 * w + 1], kb[2 * w + 1]);
+            if (do_silu) { r0 = silu_f(r0); r1 = silu_f(r1); }
+            out[w] = pack2<XD>(r0, r1);
+        }
+        char* o = yb + (size_t)(pr + 64 * i) * C * 2;
+        if constexpr (NW == 4) *reinterpret_cast<uint4*>(o) = make_uint4(out[0], out[1], out[2], out[3]);
+        else if constexpr (NW == 2) *reinterpret_cast<uint2*>(o) = make_uint2(out[0], out[1]);
+        else *reinterpret_cast<unsigned*>(o) = out[0];
+    }
+}
+
+// vector width (bytes) of gn_reg_kernel for this shape, or 0: 2-byte tensors, HW in {64, 256, 1024}, a group = nv <= 16 whole vectors
+static int gn_reg_vb(int x_dt, int y_dt, int HW, int C, int groups, bool slab) {
+    if (x_dt != y_dt || (x_dt != DT_F16 && x_dt != DT_BF16) || C % groups) return 0;
+    if (HW != 64 && HW != 256 && HW != 1024) return 0;
+    const int gb = (C / groups) * 2;   // bytes of one pixel's group
+    const int nv_max = HW == 1024 ? 8 : 16;   // 16 loads per thread: blocks of at most 512 threads (256 registers each)
+    for (int vb = 16; vb >= (slab ? 8 : 4); vb >>= 1)
+        if (gb % vb == 0 && gb / vb <= nv_max && (C * 2) % vb == 0) return vb;
+    return 0;
+}
+
+template <bool SLAB>
+static int launch_gn_reg(const void* x, int dt, void* y, const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps,
+                         int do_silu, const GnSlabSrc& src, hipStream_t s) {
+    const int vb = gn_reg_vb(dt, dt, HW, C, groups, true);
+    if (!vb) return 1;
+    const int nv = (C / groups) * 2 / vb, nl = HW / 64;
+    const dim3 grid(B * groups), block(64 * nv);
+    bool done = false;
+    auto go = [&](auto XD, auto VB, auto NL) {
+        if constexpr (SLAB && decltype(VB)::value < 8) return;
+        else {
+            hipLaunchKernelGGL((gn_reg_kernel<decltype(XD)::value, decltype(VB)::value, decltype(NL)::value, SLAB>), grid, block, 0, s, x, y, gamma, beta,
+                               HW, C, groups, nv, eps, do_silu, src);
+            done = true;
+        }
+    };
+    auto by_nl = [&](auto XD, auto VB) {
+        if (nl == 1) go(XD, VB, std::integral_constant<int, 1>{});
+        else if (nl == 4) go(XD, VB, std::integral_constant<int, 4>{});
+        else go(XD, VB, std::integral_constant<int, 16>{});
+    };
+    auto by_vb = [&](auto XD) {
+        if (vb == 16) by_nl(XD, std::integral_constant<int, 16>{});
+        else if (vb == 8) by_nl(XD, std::integral_constant<int, 8>{});
+        else by_nl(XD, std::integral_constant<int, 4>{});
+    };
+    if (dt == DT_F16) by_vb(std::integral_constant<int, DT_F16>{});
+    else by_vb(std::integral_constant<int, DT_BF16>{});
+    return done && hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // fp32 on either side, or the same 2-byte flavour on both
 template <typename F>
 bool dispatch_xy(int x_dt, int y_dt, F&& f) {
@@ -518,7 +670,14 @@ int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* pa
 }
 
 // bundle width (channels) for gn_fused_kernel, or 0 when the shape is not eligible (slab beyond the LDS budget)
+static int gn_slab_bundle(int x_dt, int HW, int C, int groups);
+// > 0 when a single-kernel GroupNorm applies to this shape (either input form): the register-resident kernel, or gn_fused_kernel's bundle
 int gn_fused_bundle(int x_dt, int HW, int C, int groups) {
+    if (C % groups) return 0;
+    if (g_gn_reg && gn_reg_vb(x_dt, x_dt, HW, C, groups, true)) return C / groups;
+    return gn_slab_bundle(x_dt, HW, C, groups);
+}
+static int gn_slab_bundle(int x_dt, int HW, int C, int groups) {
     const int VEC = x_dt == DT_F32 ? 4 : 8, EX = x_dt == DT_F32 ? 4 : 2;
     if (C % groups) return 0;
     const int cpg = C / groups;
@@ -531,7 +690,11 @@ int gn_fused_bundle(int x_dt, int HW, int C, int groups) {
 
 int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta, int B, int HW, int C, int groups,
                     float eps, int do_silu, hipStream_t s) {
-    const int BC = gn_fused_bundle(x_dt, HW, C, groups);
+    // (the same eligibility rule for both input forms: a shape must take the same kernel -- the same summation order -- whether its input
+    // is a stored tensor or a split-K GEMM's slabs: test_split_k_slabs_into_groupnorm_is_bit_identical)
+    if (g_gn_reg && gn_reg_vb(x_dt, y_dt, HW, C, groups, true))
+        return launch_gn_reg<false>(x, x_dt, y, gamma, beta, B, HW, C, groups, eps, do_silu, GnSlabSrc{}, s);
+    const int BC = gn_slab_bundle(x_dt, HW, C, groups);
     if (!BC) return 1;
     const int EX = x_dt == DT_F32 ? 4 : 2;
     const size_t smem = (size_t)HW * BC * EX + (GNF_THREADS / 64) * 4 * 2 * sizeof(double);
@@ -548,8 +711,12 @@ int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gam
 
 int launch_gn_fused_slabs(const float* slabs, int nslab, const float* bias, const float* rowvec, int rowvec_stride, int x_dt, void* y, int y_dt,
                           const float* gamma, const float* beta, int B, int HW, int C, int groups, float eps, int do_silu, hipStream_t s) {
-    const int BC = gn_fused_bundle(x_dt, HW, C, groups);
-    if (!BC || !slabs || nslab < 1 || C % 4) return 1;
+    if (!slabs || nslab < 1 || C % 4) return 1;
+    if (g_gn_reg && gn_reg_vb(x_dt, y_dt, HW, C, groups, true))
+        return launch_gn_reg<true>(nullptr, x_dt, y, gamma, beta, B, HW, C, groups, eps, do_silu,
+                                   GnSlabSrc{slabs, (long long)B * HW * C, bias, rowvec, nslab, rowvec_stride}, s);
+    const int BC = gn_slab_bundle(x_dt, HW, C, groups);
+    if (!BC) return 1;
     const int EX = x_dt == DT_F32 ? 4 : 2;
     const size_t smem = (size_t)HW * BC * EX + (GNF_THREADS / 64) * 4 * 2 * sizeof(double);
     const dim3 grid(B * (C / BC));

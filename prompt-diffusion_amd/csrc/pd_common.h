@@ -260,6 +260,7 @@ int launch_st_tail(const void* att, const void* h, const void* x_in, void* out, 
 int launch_gn_stats(const void* x, int x_dt, double* partial, int B, int HW, int C, int groups, int nchunk, hipStream_t s);
 int launch_gn_apply(const void* x, int x_dt, void* y, int y_dt, const double* partial, const float* gamma,
                     const float* beta, int B, int HW, int C, int groups, int nchunk, float eps, int silu, hipStream_t s);
+extern int g_gn_reg;   // norm.hip
 int gn_fused_bundle(int x_dt, int HW, int C, int groups);   // norm.hip: > 0 when the single-kernel GroupNorm applies
 int launch_gn_fused(const void* x, int x_dt, void* y, int y_dt, const float* gamma, const float* beta, int B, int HW, int C, int groups,
                     float eps, int do_silu, hipStream_t s);

@@ -742,6 +742,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "verbose")) { e->verbose = (int)value; return 0; }
     e->clear_graphs();   // every other knob changes what a step launches
     if (!strcmp(key, "gn_single")) { e->opt_gn_single = value != 0; return 0; }
+    if (!strcmp(key, "gn_reg")) { g_gn_reg = value != 0; return 0; }
     if (!strcmp(key, "graph")) { e->opt_graph = value != 0; return 0; }
     if (!strcmp(key, "conv_patch")) { e->opt_patch = value != 0; return 0; }
     if (!strcmp(key, "conv_patch2")) { e->opt_patch2 = value != 0; return 0; }
