@@ -256,7 +256,7 @@ struct Attn2Cfg {
     static constexpr int V_SLOTS = DH * 8;          // valid chunks of a V^T tile (8 per row of 64 keys)
     static constexpr int K_IT = (K_SLOTS + 255) / 256, V_IT = (V_SLOTS + 255) / 256;
     static constexpr int SMEM = 2 * (K_BYTES + V_BYTES);
-    static_assert(K_IT <= 3 && V_IT <= 3, "staging registers cover 3 + 3 pieces");
+    static_assert(K_IT <= 5 && V_IT <= 5, "staging registers cover 5 + 5 pieces");
     // dh padded up to the MFMA shapes leaves free slots, used to move softmax VALU work onto the matrix pipe:
     //  SUBM: a free K-dim slot of S^T = K.Q^T holds K'[key][DH] = 1 and Q'[q][DH] = -m_ref[q], so the MFMA
     //        itself delivers s - m_ref (Q is pre-scaled by scale*log2e): no per-score FMA.  m_ref is a lazily
@@ -365,14 +365,14 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
         v_lds1[i] = Cfg::K_BYTES + vt_chunk(d, s1 >> 3) + (s1 & 7) * 2;
     }
     // piece i of a tile exists for the waves with wave*64 + 256*i < SLOTS (slot counts are multiples of 64: wave-uniform)
-    uint4 kr0, kr1, kr2, vr0, vr1, vr2;   // staging registers (named: see gemm.hip)
+    uint4 kr0, kr1, kr2, kr3, kr4, vr0, vr1, vr2, vr3, vr4;   // staging registers (named: see gemm.hip); dh <= 80 uses three of each
     auto KR = [&](auto I) __attribute__((always_inline)) -> uint4& {
         constexpr int i = decltype(I)::value;
-        if constexpr (i == 0) return kr0; else if constexpr (i == 1) return kr1; else return kr2;
+        if constexpr (i == 0) return kr0; else if constexpr (i == 1) return kr1; else if constexpr (i == 2) return kr2; else if constexpr (i == 3) return kr3; else return kr4;
     };
     auto VR = [&](auto I) __attribute__((always_inline)) -> uint4& {
         constexpr int i = decltype(I)::value;
-        if constexpr (i == 0) return vr0; else if constexpr (i == 1) return vr1; else return vr2;
+        if constexpr (i == 0) return vr0; else if constexpr (i == 1) return vr1; else if constexpr (i == 2) return vr2; else if constexpr (i == 3) return vr3; else return vr4;
     };
     auto load_tile = [&](int t0) __attribute__((always_inline)) {
         const unsigned sk = (unsigned)t0 * (unsigned)p.ldk * 2u, sv = (unsigned)t0 * 2u;   // scalar tile offsets
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, WPS) void attn2_kernel(AttnParams p) {
 template <int DH, int P>
 int launch_attn2(const AttnParams& p, hipStream_t s) {
     using Cfg = Attn2Cfg<DH>;
-    auto kfn = attn2_kernel<DH, P, (DH <= 40 ? 3 : 2)>;
+    auto kfn = attn2_kernel<DH, P, (DH <= 40 ? 3 : DH <= 80 ? 2 : 1)>;
     static unsigned long long attr_done = 0;
     if (ensure_dyn_smem(reinterpret_cast<const void*>(kfn), Cfg::SMEM, &attr_done)) return 1;
     dim3 grid((p.Nq + 127) / 128, p.B * p.heads);
@@ -636,6 +636,7 @@ int launch_prec(const AttnParams& p, hipStream_t s) {
                 case 40: return launch_attn2<40, P>(p, s);
                 case 64: return launch_attn2<64, P>(p, s);
                 case 80: return launch_attn2<80, P>(p, s);
+                case 160: return launch_attn2<160, P>(p, s);   // the 16x16 / 8x8 levels (round 4)
                 default: break;
             }
         }

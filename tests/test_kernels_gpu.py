@@ -302,6 +302,7 @@ def _attn_ref(q, k, v, heads):
     (1, 1024, 1024, 320), # dh 40, self, many key tiles
     (1, 192, 192, 640),   # dh 80
     (2, 48, 77, 1280),    # dh 160, cross
+    (2, 256, 256, 1280),  # dh 160, self, four key tiles (the 16x16 level: attn2_kernel<160> in the 2-byte modes)
     (1, 12, 12, 128),     # dh 16, tiny ragged
 ])
 def test_attention(eng, B, Nq, Nk, C):
