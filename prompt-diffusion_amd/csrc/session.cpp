@@ -199,20 +199,26 @@ int pd_engine::session_setup(const pd_sample_args& a, const int64_t* t_rows, int
     // ---- guided_hint = input_hint_block(pair) + input_cond_block(query), cldm/cldm.py:306-308
     {
         Act prev_out;
-        s.hint_shared = a.use_cfg != 0;
+        s.hint_shared = a.use_cfg != 0 && (!a.pair_uncond || a.pair_uncond == a.pair) && (!a.query_uncond || a.query_uncond == a.query);
+        // both halves of the CFG batch were given the same example pair and query: the hint embedders run on B samples and guided_hint's
+        // second half is a copy of the first (option cfg_share; forward_eps)
+        const int hb = (s.hint_shared && opt_cfg_share) ? B : Bf;
+        Act hint_out = s.hint;
+        hint_out.B = hb;
         for (int which = 0; which < 2; ++which) {
             const int cin = which == 0 ? cfg.hint_channels : cfg.query_channels;
             const float* src_c = which == 0 ? a.pair : a.query;
             const float* src_u = which == 0 ? (a.pair_uncond ? a.pair_uncond : a.pair) : (a.query_uncond ? a.query_uncond : a.query);
             const size_t per = (size_t)B * cin * IH * IW;
-            Act img = new_act(Bf, IH, IW, 8, T);
+            Act img = new_act(hb, IH, IW, 8, T);
             const float* dc = stage(src_c, per);
             const float* du = (a.use_cfg && src_u != src_c) ? stage(src_u, per) : dc;
-            if (src_u != src_c) s.hint_shared = false;
             if (!arena.dry) {
                 char* dst = reinterpret_cast<char*>(img.p);
                 const size_t half = (size_t)B * IH * IW * 8 * dt_size(T);
-                if (a.use_cfg) {
+                if (hb != Bf) {
+                    if (launch_nchw_to_nhwc(dc, dst, T, B, cin, IH, IW, 8, stream)) return 1;
+                } else if (a.use_cfg) {
                     if (launch_nchw_to_nhwc(du, dst, T, B, cin, IH, IW, 8, stream)) return 1;
                     if (launch_nchw_to_nhwc(dc, dst + half, T, B, cin, IH, IW, 8, stream)) return 1;
                 } else if (launch_nchw_to_nhwc(dc, dst, T, B, cin, IH, IW, 8, stream)) return 1;
@@ -224,18 +230,20 @@ int pd_engine::session_setup(const pd_sample_args& a, const int64_t* t_rows, int
                 const ConvW& c = chain[l];
                 const int Ho = c.stride == 2 ? (cur.H + 1) / 2 : cur.H, Wo = c.stride == 2 ? (cur.W + 1) / 2 : cur.W;
                 if (l < 7) {
-                    Act o = new_act(Bf, Ho, Wo, round_up(c.cout, 8), T);
+                    Act o = new_act(hb, Ho, Wo, round_up(c.cout, 8), T);
                     if (o.C != c.cout) { pd_set_error("hint widths must be multiples of 8"); return 1; }
                     PD_TRY(conv(c, cur, o, /*silu*/ 1));
                     cur = o;
                 } else if (which == 0) {
-                    prev_out = new_act(Bf, Ho, Wo, c.cout, S);
+                    prev_out = new_act(hb, Ho, Wo, c.cout, S);
                     PD_TRY(conv(c, cur, prev_out));
                 } else {
-                    PD_TRY(conv(c, cur, s.hint, 0, 1.f, &prev_out));
+                    PD_TRY(conv(c, cur, hint_out, 0, 1.f, &prev_out));
                 }
             }
         }
+        if (hb != Bf && !arena.dry)
+            HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(s.hint.p) + hint_out.bytes(), s.hint.p, hint_out.bytes(), hipMemcpyDeviceToDevice, stream));
     }
     // ---- projected time embeddings for all rows
     PD_TRY(compute_emb(unet, s.emb_u, t_rows, n_rows, 0));
