@@ -714,10 +714,14 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         const int tiles = gemm_tiles(p.M, m.N);
         const int ktiles = fp8 ? m.Kpad8 / 128 : m.Kpad / (128 / (int)dt_size(T));
         int splitk = 1;
+        // small-M linear layers (the 8x8 level's M = 1024: 64 tiles of 128 x 160): 64 x 80 ring tiles fill the chip without split-K slabs and
+        // a finalize pass (every CU then streams 1 / 16 of the weight matrix once instead of 1 / 8 of a K slice + the slab traffic)
+        const bool small_ring = opt_ring > 0 && opt_ring_small && m.taps == 1 && !fp8 && !m.geglu && in.dt == T && ktiles <= opt_ring && tiles * 2 <= ncu &&
+                                ((p.M + 63) / 64) * ((m.N + 79) / 80) >= ncu / 2 && ring_gemm_eligible(p, P);
         // linear layers with a short K and at least half a chip of tiles: one 8-wave block per CU instead of split-K
         const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !fp8 && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;
         const int kmin = fp8 ? 8 : 16, kper = fp8 ? 4 : 8;   // an e4m3 K step carries twice the K of a 2-byte one
-        if (!dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= kmin && m.N % 4 == 0) {
+        if (!small_ring && !dense8 && !m.geglu && !VT && tiles < opt_splitk_tiles && tiles <= kTileCnt && ktiles >= kmin && m.N % 4 == 0) {
             splitk = (2 * ncu + tiles - 1) / tiles;   // about two blocks per CU
             if (splitk > ktiles / kper) splitk = ktiles / kper;
             if (splitk > opt_splitk_max) splitk = opt_splitk_max;
@@ -761,10 +765,10 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         // (almost) every CU one
         if (opt_ring > 0 && splitk == 1 && !fp8 && ktiles <= opt_ring && (p.act != 2 || opt_ring_geglu) && ring_gemm_eligible(p, P)) {
             use_ring = true;
-            ring_tile = opt_ring_tile >= 0 ? opt_ring_tile : (((p.M + 255) / 256) * ((m.N + 159) / 160) >= ncu * 7 / 8 ? 1 : 0);
+            ring_tile = opt_ring_tile >= 0 ? opt_ring_tile : small_ring ? 4 : (((p.M + 255) / 256) * ((m.N + 159) / 160) >= ncu * 7 / 8 ? 1 : 0);
             // ping-pong form (two wave groups half a K step apart; bit-identical): -10..-14 % on long reductions and -3..-5 % on one
             // 256-row tile per CU; +6..+13 % where a block walks several short tiles (the groups' epilogues serialise) -- tools/micro/ring_pp.hip
-            if (opt_ring_pp && ring_tile < 2 && p.act != 2) {
+            if (opt_ring_pp && ring_tile < 2 && p.act != 2 && !small_ring) {
                 const int bm = ring_tile ? 256 : 128;
                 const int nblk = ((p.M + bm - 1) / bm) * ((m.N + 159) / 160);
                 if (ktiles >= 40 || (ring_tile == 1 && nblk <= ncu)) ring_tile += 2;
@@ -777,6 +781,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
             const bool wide = p.big_tile == 3 && m.taps == 1 && in.dt == T;
             const int bn_cols = wide ? 320 : p.big_tile == 4 ? 192 : 160;
             ln_out->parts = ((m.N + bn_cols - 1) / bn_cols) * 2;   // 2 waves across N in every non-GEGLU tile
+            if (use_ring && ring_tile == 4) ln_out->parts = (m.N + 79) / 80;   // ... but one in the 64 x 80 ring tile
             if (ln_out->cap_parts && ln_out->parts > ln_out->cap_parts) {
                 pd_set_error("internal: %d LayerNorm statistics partials per row, buffer holds %d", ln_out->parts, ln_out->cap_parts);
                 return 1;
@@ -822,6 +827,10 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
     // fourth generation (4 waves per block, one per SIMD, 32x32x16 MFMAs, LDS-DMA operands): every unsplit 2-byte launch (-4..-8 % at
     // batch 8, -17..-19 % at batch 1 against the faster of the first two; split-K launches tie and stay on the second)
     const bool patch4 = use_patch && opt_patch4 && patch_split == 1 && conv_patch4_eligible(p, P);
+    if (verbose >= 2)   // dispatch trace (option "verbose" 2): which kernel family / tile / split a launch takes
+        fprintf(stderr, "[pdengine] gemm M %d N %d K %d taps %d stride %d ups %d: %s splitk %d big_tile %d ring_tile %d act %d R %d ln_in %d ln_out %d\n", p.M, p.N, p.K, p.taps,
+                p.stride, p.ups, use_patch ? (patch4 ? "patch4" : patch2 ? "patch2" : "patch1") : use_ring ? "ring" : "igemm", p.splitk, p.big_tile, ring_tile, p.act,
+                p.R ? 1 : 0, p.ln_stats ? 1 : 0, p.stats_out ? 1 : 0);
     if (use_patch ? (patch4 ? launch_conv_patch4(p, P, stream) : patch2 ? launch_conv_patch2(p, P, stream) : launch_conv_patch(p, P, stream))
                   : use_ring ? launch_ring_gemm(p, prec, ring_tile, stream) : launch_gemm(p, prec, stream, mid)) {
         pd_set_error("gemm launch failed: %s", hipGetErrorString(hipGetLastError()));

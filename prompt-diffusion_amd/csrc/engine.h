@@ -294,7 +294,9 @@ struct pd_engine {
     bool opt_splitk_fused = false; // split-K sums + epilogue run in the last-arriving slice instead of a finalize kernel
     int opt_splitk_max = 8;
     int opt_splitk_big = 0;       // split-K conv3x3 on 256 x 160 tiles where that still fills the chip (option "splitk_big")
-    int opt_splitk_tiles = 384;   // (x ncu / 256 at build)   // split K when the 128x160 tile grid has fewer blocks than this
+    int opt_splitk_tiles = 256;   // (x ncu / 256 at build)   // split K when the 128x160 tile grid has fewer blocks than this (one tile per CU needs no split:
+                                  // 384 sent the 16x16 level's 5120 -> 1280 feed-forward-out GEMM -- 256 tiles -- to split-K 2 + a finalize pass, 86 us; the ring
+                                  // GEMM takes it unsplit in ~60: +0.5 % end to end)
     bool opt_attn_legacy = false;  // debug: single-buffered attention kernel
     bool opt_wide = true;      // 256 x 320 GEMM tiles for large-M linear layers
     int opt_dense_tiles = 128;
@@ -304,6 +306,7 @@ struct pd_engine {
     int opt_ring_tile = -1;    // its tile: -1 auto, 0 = 128 x 160, 1 = 256 x 160
     int opt_ring_pp = 1;       // its ping-pong form where it measures faster (long K, or one 256-row tile per CU)
     int opt_ring_geglu = 1;    // GEGLU projections too (256 x 160 on 8 x 1 waves)
+    int opt_ring_small = 1;    // small-M linear layers on 64 x 80 ring tiles instead of split-K (option "ring_small")
     int opt_short_k = 20;      // linear layers with at most this many K steps: 8-wave 128x160 tile at 16 waves per CU
     bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
     int opt_patch_split_tiles = 64;

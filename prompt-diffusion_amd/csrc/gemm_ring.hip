@@ -402,7 +402,8 @@ bool ring_gemm_eligible(const GemmParams& p, int prec) {
     return true;
 }
 
-// tile: 0 = 128 x 160 (4 stages), 1 = 256 x 160 (3 stages); both 4 x 2 waves.  GEGLU layers (act 2): 256 x 160 on 8 x 1 waves.
+// tile: 0 = 128 x 160 (4 stages), 1 = 256 x 160 (3 stages); both 4 x 2 waves; 2 / 3 their ping-pong forms; 4 = 64 x 80 on 4 x 1 waves (5 stages).
+// GEGLU layers (act 2): 256 x 160 on 8 x 1 waves.
 int launch_ring_gemm(const GemmParams& p, int prec, int tile, hipStream_t s) {
     if (!ring_gemm_eligible(p, prec)) return 1;
     static int ncu_of[64] = {};   // per device id (engines on different devices share the process)
@@ -417,6 +418,9 @@ int launch_ring_gemm(const GemmParams& p, int prec, int tile, hipStream_t s) {
     }
     if (p.act == 2) {   // 256 x 160 on 8 x 1 waves (a wave: 32 rows x one GEGLU block)
         return prec == DT_F16 ? launch_ring<DT_F16, 256, 160, 8, 1, 3, true>(p, ncu, s) : launch_ring<DT_BF16, 256, 160, 8, 1, 3, true>(p, ncu, s);
+    }
+    if (tile == 4) {   // 64 x 80 on 4 x 1 waves (16 rows x 80 columns per wave), 5 stages: small-M layers (the 8x8 level's M = 1024: 256 tiles instead of 64)
+        return prec == DT_F16 ? launch_ring<DT_F16, 64, 80, 4, 1, 5>(p, ncu, s) : launch_ring<DT_BF16, 64, 80, 4, 1, 5>(p, ncu, s);
     }
     if (tile >= 2) {   // ping-pong forms: 2 = 128 x 160, 3 = 256 x 160
         if (prec == DT_F16) return tile == 3 ? launch_ring<DT_F16, 256, 160, 4, 2, 3, false, true>(p, ncu, s) : launch_ring<DT_F16, 128, 160, 4, 2, 4, false, true>(p, ncu, s);

@@ -770,6 +770,7 @@ int pd_set_option(pd_engine* e, const char* key, int64_t value) {
     if (!strcmp(key, "ring")) { e->opt_ring = (int)value; return 0; }
     if (!strcmp(key, "ring_tile")) { e->opt_ring_tile = (int)value; return 0; }
     if (!strcmp(key, "ring_geglu")) { e->opt_ring_geglu = (int)value; return 0; }
+    if (!strcmp(key, "ring_small")) { e->opt_ring_small = (int)value; return 0; }
     if (!strcmp(key, "short_k")) { e->opt_short_k = (int)value; return 0; }
     if (!strcmp(key, "patch_split")) { e->opt_patch_split = value != 0; return 0; }
     if (!strcmp(key, "ring_pp")) { e->opt_ring_pp = (int)value; return 0; }

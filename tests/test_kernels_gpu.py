@@ -174,7 +174,7 @@ def test_linear(eng, M, K, N):
     assert relerr(eng.op_linear(x, w, b, a_silu=True), O.linear(O.silu(x), w, b)) < TOL[eng.prec]
 
 
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 4])   # 128 x 160, 256 x 160, 64 x 80 (the small-M tile)
 def test_linear_ring_kernel(eng, tile):
     """gemm_ring.hip (persistent LDS-DMA ring GEMM, 2-byte modes): against the oracle and bit-identical to igemm_kernel (same MFMA
     order per accumulator) on ragged M / N, one and several tiles per block, fewer tiles than XCDs, K from 2 to 40 steps (shapes
