@@ -203,7 +203,8 @@ int pd_comm_world(pd_engine* e, int32_t* world, int32_t* rank);
 int pd_comm_all_gather(pd_engine* e, const float* send, float* recv, int64_t count, int32_t mem);
 int pd_comm_destroy(pd_engine* e); /* also done by pd_engine_destroy */
 /* Tuning / instrumentation knobs (defaults are the measured best; tests and tools/ flip them for A/B runs):
- *   "verbose", "profile" (HIP events around every contraction launch, see pd_profile_read),
+ *   "verbose" (1: workspace sizes; 2: one stderr line per contraction launch saying which kernel family / tile / split-K count it takes),
+ *   "profile" (HIP events around every contraction launch, see pd_profile_read),
  *   "two_streams" (ControlNet on a second stream beside the UNet encoder, default 1),
  *   "cfg_share" (classifier-free guidance feeds both halves of the doubled batch the same latent and timestep, ddim_hacked.py:189-192, and
  *   -- unless pair_uncond / query_uncond say otherwise -- the same example pair and query: the layers in front of the first
