@@ -292,7 +292,7 @@ struct pd_engine {
     Session ses;
     int verbose = 0;
     bool opt_splitk_fused = false; // split-K sums + epilogue run in the last-arriving slice instead of a finalize kernel
-    int opt_splitk_max = 8;
+    int opt_splitk_max = 16;   // (8 until the end of round 4: the 8x8 level at batch 1 -- M = 128, 8 tiles -- then ran on 64 blocks; 16: +1.5 % at batch 1, nothing at batch 8)
     int opt_splitk_big = 0;       // split-K conv3x3 on 256 x 160 tiles where that still fills the chip (option "splitk_big")
     int opt_splitk_tiles = 256;   // (x ncu / 256 at build)   // split K when the 128x160 tile grid has fewer blocks than this (one tile per CU needs no split:
                                   // 384 sent the 16x16 level's 5120 -> 1280 feed-forward-out GEMM -- 256 tiles -- to split-K 2 + a finalize pass, 86 us; the ring
