@@ -234,8 +234,8 @@ int pd_comm_destroy(pd_engine* e); /* also done by pd_engine_destroy */
  *   "st_fuse" (320-channel SpatialTransformer blocks: st_front / st_tail fused kernels in the 2-byte modes, 1),
  *   "ring" / "ring_tile" / "ring_geglu" (gemm_ring.hip: linear layers over 2-byte operands with at most that many 64-element K steps
  *   take the persistent LDS-DMA ring GEMM, 80 / its tile -1 auto, 0 = 128x160, 1 = 256x160 / GEGLU projections too, 1; results are
- *   bit-identical to the igemm tiles'), "ring_small" (small-M linear layers -- at most half a chip of 128x160 tiles, the 8x8 level's M = 1024 --
- *   on 64x80 ring tiles without split-K slabs and a finalize pass, 1), "ring_pp" (its ping-pong form -- two wave groups half a K step apart -- for K >= 2560 and for one
+ *   bit-identical to the igemm tiles'), "ring_small" (small-M linear layers -- at most a quarter chip of 128x160 tiles, the 8x8 level's M = 1024 --
+ *   on 64x80 ring tiles without split-K slabs and a finalize pass: 0 off, d = where the 128x160 grid fills at most 1/d of the chip, 4), "ring_pp" (its ping-pong form -- two wave groups half a K step apart -- for K >= 2560 and for one
  *   256-row tile per CU, 1; bit-identical), "slab_gn" (a ResBlock conv1 that runs split-K hands its fp32 slabs to the single-kernel
  *   GroupNorm that reads them instead of running a finalize pass, 1; bit-identical), "patch_split_min" (patch-conv split-K: at
  *   least this many 128-byte channel chunks per slice, 4). */

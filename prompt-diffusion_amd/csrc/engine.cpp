@@ -716,7 +716,7 @@ int pd_engine::gemm(const WMat& m, const Act& in, Act& out, int stride, int ups,
         int splitk = 1;
         // small-M linear layers (the 8x8 level's M = 1024: 64 tiles of 128 x 160): 64 x 80 ring tiles fill the chip without split-K slabs and
         // a finalize pass (every CU then streams 1 / 16 of the weight matrix once instead of 1 / 8 of a K slice + the slab traffic)
-        const bool small_ring = opt_ring > 0 && opt_ring_small && m.taps == 1 && !fp8 && !m.geglu && in.dt == T && ktiles <= opt_ring && tiles * 2 <= ncu &&
+        const bool small_ring = opt_ring > 0 && opt_ring_small && m.taps == 1 && !fp8 && !m.geglu && in.dt == T && ktiles <= opt_ring && tiles * opt_ring_small <= ncu &&
                                 ((p.M + 63) / 64) * ((m.N + 79) / 80) >= ncu / 2 && ring_gemm_eligible(p, P);
         // linear layers with a short K and at least half a chip of tiles: one 8-wave block per CU instead of split-K
         const bool dense8 = opt_dense_k > 0 && m.taps == 1 && in.dt == T && !fp8 && !m.geglu && ktiles <= opt_dense_k && tiles >= opt_dense_tiles;

@@ -306,7 +306,7 @@ struct pd_engine {
     int opt_ring_tile = -1;    // its tile: -1 auto, 0 = 128 x 160, 1 = 256 x 160
     int opt_ring_pp = 1;       // its ping-pong form where it measures faster (long K, or one 256-row tile per CU)
     int opt_ring_geglu = 1;    // GEGLU projections too (256 x 160 on 8 x 1 waves)
-    int opt_ring_small = 1;    // small-M linear layers on 64 x 80 ring tiles instead of split-K (option "ring_small")
+    int opt_ring_small = 4;    // small-M linear layers on 64 x 80 ring tiles instead of split-K (option "ring_small"): 0 off, d: where the 128 x 160 grid fills at most 1 / d of the chip
     int opt_short_k = 20;      // linear layers with at most this many K steps: 8-wave 128x160 tile at 16 waves per CU
     bool opt_patch_split = true;      // LDS-patch conv with the channel chunks split over 2-4 slices (16x16 level)
     int opt_patch_split_tiles = 64;
