@@ -1,5 +1,6 @@
+"""The 64x64 320 -> 320 patch conv at batch 16 / 8 / 4 / 2 under every kernel generation (the half-batch launches of the shared CFG front)."""
 import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from prompt_diffusion_amd import engine as E, weights as W
 for opts in ({}, {"patch4": 0}, {"patch4": 0, "conv_patch2": 0}, {"patch4":0, "conv_patch2_tiles": 1}):
     e = E.Engine(W.TINY, precision="f16")
