@@ -1,7 +1,8 @@
 import os, sys, numpy as np
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from prompt_diffusion_amd import engine as E, weights as W
-g = np.load("/root/repo/tests/golden/net_sd15_b1_32x32_s50.npz")
+g = np.load(os.path.join(ROOT, "tests", "golden", "net_sd15_b1_32x32_s50.npz"))
 cfg = W.SD15
 B, h, w, S = int(g["B"]), int(g["h"]), int(g["w"]), int(g["S"])
 keep = [int(k) for k in g["keep"]]; ref = {k: g["x_inter"][j] for j, k in enumerate(keep)}
